@@ -1,0 +1,204 @@
+"""Pin the C oracle (oracle/mz_oracle.c) against golden traces recorded from the reference's own
+MCTS.run / select_action / store_search_statistics (tests/golden/make_golden.py).
+
+"Injected" mode: the per-simulation network outputs (value, reward, priors) are replayed from the
+fixture, so everything the tree does -- UCB arithmetic in fp64, tie-breaks, the RNG stream,
+visit counts, value sums, min-max statistics -- must be BIT-EXACT.
+"""
+import numpy
+import pytest
+
+TRACE_FILES = ["g4_cartpole_traces", "g5_tictactoe_traces", "g5_connect4_traces",
+               "g5_cartpole_ties_traces"]
+
+
+def replay_trace(oracle, fx, i):
+    cfg = oracle.config_from_fixture(fx)
+    n_legal = int(fx["n_legal"][i])
+    legal = fx["legal"][i][:n_legal]
+    rng = oracle.Rng(int(fx["seed"][i]))
+    tree = oracle.Tree(cfg)
+    noise = tree.reset(rng, legal, int(fx["to_play"][i]), float(fx["root_reward"][i]),
+                       root_priors=fx["root_priors"][i][:n_legal], add_noise=True)
+    tree.simulate(rng, value=fx["sim_value"][i], reward=fx["sim_reward"][i],
+                  priors=fx["sim_priors"][i])
+    return tree, rng, noise, n_legal
+
+
+@pytest.mark.parametrize("name", TRACE_FILES)
+def test_injected_traces_bit_exact(oracle, golden, name):
+    fx = golden(name)
+    T = len(fx["seed"])
+    for i in range(T):
+        tree, rng, noise, n = replay_trace(oracle, fx, i)
+        st = tree.root_stats()
+        assert numpy.array_equal(noise[:n], fx["noise"][i][:n]), (name, i)
+        assert numpy.array_equal(st["visits"], fx["visits"][i][:n]), (name, i)
+        assert numpy.array_equal(st["child_value_sum"], fx["child_value_sum"][i][:n]), (name, i)
+        assert numpy.array_equal(st["child_prior"], fx["child_prior"][i][:n]), (name, i)
+        assert numpy.array_equal(st["child_reward"], fx["child_reward"][i][:n]), (name, i)
+        assert st["root_value_sum"] == fx["root_value_sum"][i]
+        assert st["root_visit"] == fx["root_visit"][i] == int(fx["cfg_S"])
+        assert st["max_tree_depth"] == fx["max_tree_depth"][i]
+        assert st["mms_min"] == fx["mms_min"][i] and st["mms_max"] == fx["mms_max"][i]
+        # per-simulation path, tie-list sizes and RNG consumption
+        assert numpy.array_equal(tree.sim_depth, fx["sim_depth"][i])
+        assert numpy.array_equal(tree.sim_actions, fx["sim_actions"][i])
+        assert numpy.array_equal(tree.sim_ties, fx["sim_ties"][i])
+        assert rng.words == fx["rng_words_run"][i]
+        # targets (store_search_statistics) and the sampled action
+        cv, rv = tree.search_statistics()
+        assert numpy.array_equal(cv, fx["child_visits_target"][i])
+        assert rv == fx["root_value_target"][i]
+        slot = oracle.select_action(rng, st["visits"], float(fx["temperature"][i]))
+        assert int(fx["legal"][i][slot]) == fx["action_T"][i]
+        assert rng.words == fx["rng_words_run"][i] + fx["rng_words_select"][i]
+
+
+def test_survey_sample(oracle, golden):
+    """SURVEY.md section 8c sample: CartPole checkpoint, obs [0.01,-0.02,0.03,0.04], seeds 0..3."""
+    fx = golden("g4_cartpole_traces")
+    assert fx["visits"][:4].tolist() == [[7, 43], [17, 33], [9, 41], [12, 38]]
+    tree, rng, noise, n = replay_trace(oracle, fx, 0)
+    st = tree.root_stats()
+    assert st["visits"].tolist() == [7, 43]
+    assert st["child_prior"].tolist() == [0.38765144048778205, 0.612348559512218]
+    assert st["root_value_sum"] / st["root_visit"] == 103.43967241245127
+    assert fx["root_predicted_value"][0] == 103.25457763671875
+    assert st["max_tree_depth"] == 8
+
+
+def test_root_priors_from_logits_match_reference_softmax(oracle, golden):
+    """Node.expand's fp32 softmax over the legal logits, as restated in C, against the priors
+    torch produced in the reference run (pre-noise priors are recoverable from the fixture)."""
+    for name in TRACE_FILES[:3]:
+        fx = golden(name)
+        frac = float(fx["cfg_frac"])
+        for i in range(len(fx["seed"])):
+            n = int(fx["n_legal"][i])
+            legal = fx["legal"][i][:n]
+            sm = oracle.softmax_f32(fx["root_policy_logits"][i][legal]).astype(numpy.float64)
+            numpy.testing.assert_allclose(sm, fx["root_priors"][i][:n], rtol=0, atol=2e-7)
+            noisy = fx["root_priors"][i][:n] * (1 - frac) + fx["noise"][i][:n] * frac
+            assert numpy.array_equal(noisy, fx["child_prior"][i][:n])
+
+
+def test_lock_step_simulation_equals_one_shot(oracle, golden):
+    fx = golden("g5_tictactoe_traces")
+    i = 5
+    cfg = oracle.config_from_fixture(fx)
+    n = int(fx["n_legal"][i])
+    rng = oracle.Rng(int(fx["seed"][i]))
+    tree = oracle.Tree(cfg)
+    tree.reset(rng, fx["legal"][i][:n], int(fx["to_play"][i]), float(fx["root_reward"][i]),
+               root_priors=fx["root_priors"][i][:n])
+    for s in range(cfg.S):
+        tree.simulate(rng, first=s, n=1, value=fx["sim_value"][i], reward=fx["sim_reward"][i],
+                      priors=fx["sim_priors"][i])
+    assert numpy.array_equal(tree.root_stats()["visits"], fx["visits"][i][:n])
+
+
+def test_plugin_contract_errors(oracle, golden):
+    fx = golden("g5_tictactoe_traces")
+    cfg = oracle.config_from_fixture(fx)
+    tree = oracle.Tree(cfg)
+    rng = oracle.Rng(0)
+    with pytest.raises(AssertionError, match="should not be an empty array"):
+        tree.reset(rng, [], 0, 0.0, root_policy_logits=fx["root_policy_logits"][0])
+    with pytest.raises(AssertionError, match="subset of the action space"):
+        tree.reset(rng, [0, 9], 0, 0.0, root_policy_logits=fx["root_policy_logits"][0])
+
+
+def test_select_action_g8(oracle, golden):
+    fx = golden("g8_select_action")
+    for i in range(int(fx["n_sets"])):
+        visits, actions = fx[f"set{i}_visits"], fx[f"set{i}_actions"]
+        for T in (0, 0.25, 0.5, 1.0, 0.7, float("inf")):
+            rng = oracle.Rng(100 + i)
+            picks = [int(actions[oracle.select_action(rng, visits, T)]) for _ in range(12)]
+            assert picks == fx[f"set{i}_T{T}"].tolist(), (i, T)
+
+
+def test_stacked_observations_g9(oracle, golden):
+    fx = golden("g9_stacked_observations")
+    obs, acts = list(fx["observations"]), fx["actions"].tolist()
+    for n_stack in (0, 2, 4):
+        for idx in (-1, 0, 1, 3, 5):
+            got = oracle.get_stacked_observations(obs, acts, idx, n_stack)
+            assert numpy.array_equal(numpy.asarray(got, dtype="float32"), fx[f"stack{n_stack}_idx{idx}"])
+
+
+def test_oracle_support_to_scalar_g1(oracle, golden):
+    fx = golden("g1_support_to_scalar")
+    numpy.testing.assert_allclose(oracle.support_to_scalar(fx["logits21"], 10), fx["out21"][:, 0],
+                                  rtol=1e-5, atol=1e-5)
+    # F = 601 (atari.py support 300): the inverse transform subtracts 1 from a sqrt near 1 and
+    # squares, so fp32 summation-order noise in sum(support * p) is amplified ~10x; 1e-4 here.
+    numpy.testing.assert_allclose(oracle.support_to_scalar(fx["logits601"], 300), fx["out601"][:, 0],
+                                  rtol=1e-4, atol=2e-4)
+    assert numpy.all(oracle.support_to_scalar(fx["logits_init"], 10) == 0.0)
+    assert numpy.all(fx["out_init"] == 0.0)
+
+
+def test_oracle_fc_network_g2(oracle, golden):
+    """C restatement of the fully-connected network vs the reference's torch outputs (1e-5)."""
+    fx = golden("g2_fc_inference")
+    w = golden("cartpole_weights")
+    net = oracle.FcNet({k: w[k] for k in w.files}, 4, 8, 2, 10, [], [16], [16], [16], [16])
+    for b in range(len(fx["obs"])):
+        v, r, p, h = net.initial(fx["obs"][b])
+        numpy.testing.assert_allclose(h, fx["init_hidden"][b], rtol=1e-5, atol=1e-5)
+        numpy.testing.assert_allclose(p, fx["init_policy"][b], rtol=1e-5, atol=1e-5)
+        numpy.testing.assert_allclose(v, fx["init_value"][b], rtol=1e-5, atol=2e-5)
+        assert numpy.array_equal(r, fx["init_reward"][b])
+        v, r, p, h = net.recurrent(fx["init_hidden"][b], int(fx["actions"][b, 0]))
+        numpy.testing.assert_allclose(h, fx["rec_hidden"][b], rtol=1e-5, atol=1e-5)
+        numpy.testing.assert_allclose(p, fx["rec_policy"][b], rtol=1e-5, atol=1e-5)
+        numpy.testing.assert_allclose(v, fx["rec_value"][b], rtol=1e-5, atol=2e-5)
+        numpy.testing.assert_allclose(r, fx["rec_reward"][b], rtol=1e-5, atol=2e-5)
+
+
+def test_oracle_native_fc_run_matches_reference_targets(oracle, golden):
+    """Oracle end to end with its OWN fp32 network (no replayed values) vs the reference run.
+
+    Tolerances: network outputs agree to 1e-5 (test above); the decoded value scalar near 100
+    agrees to ~1.2e-5 relative because the inverse value transform (models.py:657-661) subtracts 1
+    from sqrt(1 + 0.004(|x|+1.001)) ~ 1.02 and squares: a 1-ulp (6e-8) change of the categorical
+    expectation x is amplified ~100x.  So value targets are held to 3e-5 relative wherever both
+    runs walked identical paths; policy targets (visit ratios) are then exactly equal.
+    """
+    import ctypes
+    fx = golden("g4_cartpole_traces")
+    w = golden("cartpole_weights")
+    net = oracle.FcNet({k: w[k] for k in w.files}, 4, 8, 2, 10, [], [16], [16], [16], [16])
+    cfg = oracle.config_from_fixture(fx, H=8)
+    T = len(fx["seed"])
+    same_paths = 0
+
+    def cb(user, hid, a, vl, rl, pl, nh):
+        v2, r2, p2, h2 = net.recurrent(numpy.ctypeslib.as_array(hid, (8,)), a)
+        numpy.ctypeslib.as_array(vl, (21,))[:] = v2
+        numpy.ctypeslib.as_array(rl, (21,))[:] = r2
+        numpy.ctypeslib.as_array(pl, (2,))[:] = p2
+        numpy.ctypeslib.as_array(nh, (8,))[:] = h2
+
+    for i in range(T):
+        rng = oracle.Rng(int(fx["seed"][i]))
+        v, r, p, h = net.initial(fx["obs"][i])
+        tree = oracle.Tree(cfg)
+        tree.reset(rng, [0, 1], 0, float(oracle.support_to_scalar(r[None], 10)[0]),
+                   root_policy_logits=p, root_hidden=h)
+        tree.simulate(rng, callback=cb)
+        if not numpy.array_equal(tree.sim_actions, fx["sim_actions"][i]):
+            continue
+        same_paths += 1
+        st = tree.root_stats()
+        assert numpy.array_equal(st["visits"], fx["visits"][i])
+        cv, rv = tree.search_statistics()
+        assert numpy.array_equal(cv, fx["child_visits_target"][i])
+        assert abs(rv - fx["root_value_target"][i]) <= 3e-5 * max(1.0, abs(fx["root_value_target"][i]))
+        numpy.testing.assert_allclose(tree.sim_value, fx["sim_value"][i], rtol=3e-5, atol=1e-5)
+        numpy.testing.assert_allclose(tree.sim_priors, fx["sim_priors"][i], rtol=0, atol=1e-5)
+        slot = oracle.select_action(rng, st["visits"], float(fx["temperature"][i]))
+        assert slot == fx["action_T"][i]
+    assert same_paths >= 0.9 * T, f"identical-path rate {same_paths}/{T}"
