@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS simulations/sec (whole job) on BASELINE.json config #2 --
+CartPole-v1, fully-connected net (the reference's trained checkpoint), 4096 envs x 50 sims per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one move of self-play search for every env on the rank: root inference + root expansion
+with Dirichlet noise, 50 x (select -> recurrent_inference -> expand/backup), readout, action sampling
+(synthetic fixed-weight rollouts, observations uniform(-0.05, 0.05) resident in HBM).
+value = (ranks x envs x sims x steps) / max-over-ranks wall time; weak scaling (fixed envs per GPU);
+each rank owns envs [rank*E, (rank+1)*E) with RNG seeds config.seed + global env index, and every
+`--bcast-every` steps all ranks take rank 0's flat weight buffer by RCCL broadcast.
+
+Prints ONE JSON line (rank 0).  Extra legs on rank 0:
+  roofline      HIP-event-bracketed eager pass of the same workload (events cannot bracket kernels
+                inside a replayed hipGraph): per-kernel mean duration, algorithmic bytes per launch
+                (SURVEY.md section 8d formula with the measured mean select depth) -> achieved GB/s vs 8 TB/s
+  cpu_baseline  N=1 only: the C oracle (a port of the reference's one-tree-at-a-time loop) on one host
+                core over a bounded sample of the same observations
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# oracle-port / reference ratio measured in the build container on the same inputs (1 thread, Xeon
+# 2.1 GHz): C port 324e3 sims/s vs reference Python 1559 sims/s (tests/golden/g10_reference_speed.npz)
+RHO_PORT_OVER_REFERENCE = 208.0
+
+
+def pkg(sub):
+    return importlib.import_module(f"muzero-hypermodel_amd.{sub}")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=4096, help="envs (trees) per GPU")
+    ap.add_argument("--bcast-every", type=int, default=10, help="weight broadcast period in steps (N>1)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--obs-sets", type=int, default=8)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    from parity_helpers import load_golden
+    actor_mod, cartpole = pkg("actor"), pkg("games.cartpole")
+    rank, world, local_rank = actor_mod.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    config = cartpole.MuZeroConfig()
+    E, S, A = args.envs, config.num_simulations, len(config.action_space)
+    w = load_golden("cartpole_weights")
+    weights = {k: torch.from_numpy(w[k]) for k in w.files}
+    actor = actor_mod.SearchActor(config, weights, E, rank=rank, device=device, use_graph=not args.no_graph)
+    engine, model = actor.engine, actor.model
+
+    rs = np.random.RandomState(123 + rank)
+    obs_sets = [torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).to(device)
+                for _ in range(args.obs_sets)]
+    legal = [[0, 1]] * E
+    to_play = [0] * E
+
+    def one_step(i):
+        if world > 1 and args.bcast_every and i % args.bcast_every == 0:
+            actor.refresh_weights(src=0)
+        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True)
+        engine.sample_actions(1.0)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sims_total = world * E * S * args.steps
+    value = sims_total / elapsed
+
+    result = {
+        "metric": "mcts_simulations_per_sec", "value": value, "unit": "simulations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "cartpole_fc_4096envs_x_50sims", "envs_per_gpu": E, "simulations": S,
+                   "actions": A, "network": "fullyconnected (reference checkpoint, fp32 inference)",
+                   "launch": "eager" if args.no_graph else "hipgraph", "parallelism": f"actors{world}",
+                   "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
+        "self_play_moves_per_sec": world * E * args.steps / elapsed,
+    }
+
+    if rank == 0:
+        if args.profile_steps > 0:
+            result["roofline"], result["kernels"] = roofline_leg(engine, one_step, args.profile_steps, device)
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline_leg(config, w, args.cpu_seconds)
+            result["speedup_vs_reference_equivalent"] = value / result["cpu_baseline"]["reference_equivalent_value"]
+    barrier()
+    if rank == 0:
+        print(json.dumps(result))
+    actor.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def roofline_leg(engine, one_step, steps, device):
+    """Eager pass with HIP events around every tree-kernel launch (same stream as the launches)."""
+    engine.set_profiling(True)
+    engine.get_profile(reset=True)
+    for i in range(2):
+        one_step(i)
+    torch.cuda.synchronize(device)
+    engine.get_profile(reset=True)
+    for i in range(steps):
+        one_step(i)
+    torch.cuda.synchronize(device)
+    prof = engine.get_profile(reset=True)
+    engine.set_profiling(False)
+    sims = max(prof["simulations"], 1)
+    mean_depth = prof["select_depth_sum"] / sims
+    bytes_sim = engine.algorithmic_bytes_per_simulation(mean_depth)
+    kernels = {}
+    for name, ms_key, n_key in (("select", "select_ms", "select_launches"),
+                                ("expand_backup", "expand_backup_ms", "expand_backup_launches")):
+        launches = max(prof[n_key], 1)
+        avg_us = 1e3 * prof[ms_key] / launches
+        per_launch = bytes_sim[name] * engine.E
+        kernels[name] = {"avg_us": avg_us, "launches": prof[n_key], "algorithmic_bytes_per_launch": per_launch,
+                         "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
+    d = kernels[dominant]
+    roofline = {"bound": "hbm", "kernel": f"mz::{dominant}_kernel", "achieved": d["achieved_GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
+                "traffic": None, "avg_kernel_us": d["avg_us"], "mean_select_depth": mean_depth,
+                "algorithmic_bytes_per_simulation": bytes_sim,
+                "timing": "hip events on the launch stream, eager pass of the same steps "
+                          "(the value-region replays a hipGraph, which events cannot subdivide)",
+                "working_set_bytes": engine.device_bytes()}
+    return roofline, kernels
+
+
+def cpu_baseline_leg(config, w, seconds):
+    """The oracle's C port of the reference loop, one host core, bounded sample of the same workload."""
+    import mz_oracle
+    weights = {k: w[k] for k in w.files}
+    net = mz_oracle.FcNet.from_config(config, weights)
+    cfg = mz_oracle.config_from_muzero(config, H=config.encoding_size)
+    obs = np.random.RandomState(123).uniform(-0.05, 0.05, (4096, 1, 1, 4)).astype(np.float32)
+    rng = mz_oracle.Rng(config.seed)
+    mz_oracle.fc_selfplay_moves(cfg, net, rng, obs[:64], 1.0)  # warm
+    t0 = time.perf_counter()
+    sims, moves = 0, 0
+    while time.perf_counter() - t0 < seconds:
+        out = mz_oracle.fc_selfplay_moves(cfg, net, rng, obs[:1024], 1.0)
+        sims += out["sims"]
+        moves += 1024
+    dt = time.perf_counter() - t0
+    try:
+        cpu_model = [line.split(":", 1)[1].strip() for line in open("/proc/cpuinfo") if line.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    return {"value": sims / dt, "unit": "simulations/s", "cores": 1, "kind": "port",
+            "sample": f"{moves} moves x {config.num_simulations} sims ({dt:.1f} s), same weights and "
+                      "observation distribution, one tree at a time",
+            "cpu": cpu_model, "host_cores_available": os.cpu_count(),
+            "rho_port_over_reference": RHO_PORT_OVER_REFERENCE,
+            "reference_equivalent_value": sims / dt / RHO_PORT_OVER_REFERENCE}
+
+
+if __name__ == "__main__":
+    main()

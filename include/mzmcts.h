@@ -1,0 +1,219 @@
+/*
+ * mzmcts.h -- C ABI of the MI355X batched-MCTS engine (libmzmcts.so).
+ *
+ * This is the drop-in boundary for the self-play / MCTS hot path of
+ * jiawei415/muzero-hypermodel (a snapshot of muzero-general).  The reference has no native code:
+ * its "FFI" for this path is the Python surface of self_play.py.  Each entry point below names the
+ * reference code it replaces (file:line relative to the reference root).  The Python host in
+ * muzero-hypermodel_amd/ binds these symbols with ctypes (muzero-hypermodel_amd/_native.py) and
+ * re-creates the reference classes (SelfPlay / MCTS / Node / GameHistory / MinMaxStats) on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  "dev" pointers are HIP device pointers whose
+ *     lifetime the caller guarantees for the duration of the call (torch tensors cross as
+ *     tensor.data_ptr()); "host" pointers are ordinary host memory.
+ *   - every function that launches work takes the hipStream_t to launch on as `void *stream`
+ *     (0 = the null stream).  Kernels are asynchronous; functions documented as "blocking" synchronise
+ *     that stream before returning.  Launch functions perform no allocation and no synchronisation,
+ *     so they may be captured into a hipGraph.
+ *   - one caller thread and one stream per engine; one engine (process) per GPU
+ *     (reference: one single-threaded Ray actor per worker, self_play.py:11-29).
+ *   - return value: 0 = ok, < 0 = error; mzmcts_last_error() gives the message.  Plugin-contract
+ *     violations use the reference's assertion texts (self_play.py:297-302).
+ *   - E trees are searched in lock step.  Tree e uses RNG stream e, a clone of numpy's legacy
+ *     RandomState seeded like reference worker `config.seed + e` (muzero.py:175, self_play.py:22).
+ *   - child statistics are indexed by child SLOT: slot i of the root is the i-th entry of the
+ *     legal-action list handed to mzmcts_begin_search (the reference's dict insertion order,
+ *     self_play.py:303-309, 464-466); below the root slot == action (self_play.py:346-352).
+ */
+#ifndef MZMCTS_H
+#define MZMCTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZMCTS_ABI_VERSION 1
+
+/* error codes */
+#define MZMCTS_OK 0
+#define MZMCTS_ERR_INVALID (-1)      /* bad argument / bad call order */
+#define MZMCTS_ERR_HIP (-2)          /* HIP runtime failure (no device, OOM, launch error) */
+#define MZMCTS_ERR_EMPTY_LEGAL (-3)  /* "Legal actions should not be an empty array." */
+#define MZMCTS_ERR_LEGAL_RANGE (-4)  /* "Legal actions should be a subset of the action space." */
+#define MZMCTS_ERR_PLAYERS (-5)      /* "More than two player mode not implemented." */
+
+typedef struct mzmcts_engine mzmcts_engine;
+
+/* Fields of MuZeroConfig the tree kernels read (games/cartpole.py:21-46 etc.). */
+typedef struct mzmcts_config {
+    int32_t num_envs;        /* E: trees searched in lock step on this GPU                    */
+    int32_t num_actions;     /* A = len(config.action_space)                                  */
+    int32_t num_simulations; /* S = config.num_simulations                                    */
+    int32_t num_players;     /* len(config.players): 1 or 2 (self_play.py:412-431)            */
+    int32_t support_size;    /* config.support_size; F = 2*support_size+1 logits              */
+    int32_t hidden_floats;   /* H: fp32 values per hidden state (0 = engine keeps no states)  */
+    int32_t device;          /* HIP device ordinal                                            */
+    int32_t reserved;
+    double discount;                  /* config.discount                                      */
+    double pb_c_base;                 /* config.pb_c_base                                     */
+    double pb_c_init;                 /* config.pb_c_init                                     */
+    double root_dirichlet_alpha;      /* config.root_dirichlet_alpha                          */
+    double root_exploration_fraction; /* config.root_exploration_fraction                     */
+    void *hidden_pool; /* optional caller-owned dev buffer f32[(S+1), E, H] (e.g. a torch tensor the
+                          network writes next states into); NULL = the engine allocates it       */
+} mzmcts_config;
+
+/* Root statistics of every tree after a search, host arrays filled by mzmcts_readout().
+ * Any pointer may be NULL.  What the reference reads off `root` after MCTS.run
+ * (self_play.py:230-233, 500-510; diagnose_model.py:36-72). */
+typedef struct mzmcts_root_stats {
+    int32_t *visits;          /* [E,A] child.visit_count per slot                              */
+    double *child_value_sum;  /* [E,A] child.value_sum                                         */
+    double *child_prior;      /* [E,A] child.prior (after exploration noise)                   */
+    double *child_reward;     /* [E,A] child.reward                                            */
+    int32_t *child_expanded;  /* [E,A] 1 if the child was expanded (has a hidden state)        */
+    double *root_value_sum;   /* [E]   root.value_sum                                          */
+    int32_t *root_visits;     /* [E]   root.visit_count                                        */
+    int32_t *max_tree_depth;  /* [E]   mcts_info["max_tree_depth"]                             */
+    double *root_predicted_value; /* [E] mcts_info["root_predicted_value"]                     */
+    double *min_max;          /* [E,2] MinMaxStats.minimum, .maximum                           */
+    int64_t *depth_sum;       /* [E]   sum over simulations of the select depth (for d-bar)    */
+    uint32_t *tie_break_words;/* [E]   32-bit RNG words the tie-breaks of this search drew     */
+} mzmcts_root_stats;
+
+/* HIP-event timings accumulated while profiling is on (bench.py roofline leg). */
+typedef struct mzmcts_profile {
+    double select_ms, expand_backup_ms, root_ms; /* summed kernel-bracket times           */
+    int64_t select_launches, expand_backup_launches, root_launches;
+    int64_t select_depth_sum;  /* sum over launches and trees of the select depth (d-bar) */
+    int64_t simulations;       /* tree-simulations executed (launches x active trees)     */
+} mzmcts_profile;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * Replaces SelfPlay.__init__'s per-worker state (self_play.py:17-29) and the per-move
+ * `MCTS(config)` / `Node(0)` / `MinMaxStats()` allocations (self_play.py:145, 280, 317): the
+ * engine owns every device pool for the actor's lifetime and recycles them per move. */
+int mzmcts_abi_version(void);
+int mzmcts_create(const mzmcts_config *config, mzmcts_engine **out);
+void mzmcts_destroy(mzmcts_engine *engine);
+const char *mzmcts_last_error(const mzmcts_engine *engine); /* engine may be NULL (create errors) */
+
+/* ---- RNG streams (numpy.random.seed / get_state / set_state; self_play.py:22) ---------------
+ * seeds: host u32[E]; stream e behaves like `numpy.random.seed(seeds[e])`.  Blocking. */
+int mzmcts_seed(mzmcts_engine *engine, const uint32_t *seeds, void *stream);
+/* Exchange one stream with numpy's global generator state (key[624], pos, has_gauss, gauss) so a
+ * single-env facade interleaves exactly with other users of numpy.random.  Blocking. */
+int mzmcts_rng_set_state(mzmcts_engine *engine, int32_t env, const uint32_t *key, int32_t pos,
+                         int32_t has_gauss, double cached_gaussian, void *stream);
+int mzmcts_rng_get_state(mzmcts_engine *engine, int32_t env, uint32_t *key, int32_t *pos,
+                         int32_t *has_gauss, double *cached_gaussian, void *stream);
+
+/* ---- one search = MCTS.run (self_play.py:261-362) -------------------------------------------
+ * begin_search: host side of the root set-up (self_play.py:297-315).
+ *   legal_actions host i32[E,A]: row e holds num_legal[e] actions in the plugin's order
+ *   num_legal     host i32[E];   0 marks env e inactive for this search (no RNG use, no work)
+ *   to_play       host i32[E]:   Game.to_play() per env
+ *   Draws the Dirichlet noise for every active env from its RNG stream (numpy legacy gamma
+ *   sampler, host libm) when add_exploration_noise != 0 and queues the uploads on `stream`.
+ *   noise_out (optional host f64[E,A]) receives the noise vectors. */
+int mzmcts_begin_search(mzmcts_engine *engine, const int32_t *legal_actions, const int32_t *num_legal,
+                        const int32_t *to_play, int32_t add_exploration_noise, double *noise_out,
+                        void *stream);
+
+/* expand_roots: device side of root.expand + add_exploration_noise (self_play.py:293-315,
+ * 452-477) from initial_inference outputs (models.py:172-190):
+ *   value_logits  dev f32[E,F]  -> root_predicted_value via support_to_scalar (models.py:641-662)
+ *   reward_logits dev f32[E,F] or NULL (NULL = reward 0, what log(one_hot) decodes to)
+ *   policy_logits dev f32[E,A]  -> fp32 softmax over the legal logits only
+ *   root_hidden   dev f32[E,H] or NULL when the caller wrote pool slab 0 in place */
+int mzmcts_expand_roots(mzmcts_engine *engine, const float *value_logits, const float *reward_logits,
+                        const float *policy_logits, const float *root_hidden, void *stream);
+/* Injected-mode root (parity tests): reward dev f64[E], pre-noise priors dev f64[E,A] per slot. */
+int mzmcts_expand_roots_injected(mzmcts_engine *engine, const double *root_reward,
+                                 const double *root_priors, void *stream);
+
+/* select: the `while node.expanded()` descent with select_child / ucb_score for all E trees
+ * (self_play.py:321-335, 364-405) plus the gather of the parent hidden states into one contiguous
+ * batch for recurrent_inference (self_play.py:339-343):
+ *   parent_hidden_out dev f32[E,H] or NULL (skip the gather), action_out dev i64[E] or NULL */
+int mzmcts_select(mzmcts_engine *engine, float *parent_hidden_out, int64_t *action_out, void *stream);
+
+/* expand_backup: support_to_scalar on value/reward (self_play.py:344-345), node.expand over the
+ * full action space (self_play.py:346-352, 452-466), backpropagate with MinMaxStats
+ * (self_play.py:354, 407-431, 560-562), max_tree_depth (self_play.py:356).
+ *   value_logits/reward_logits dev f32[E,F], policy_logits dev f32[E,A],
+ *   next_hidden dev f32[E,H] or NULL when the caller wrote slab mzmcts_next_slab() in place. */
+int mzmcts_expand_backup(mzmcts_engine *engine, const float *value_logits, const float *reward_logits,
+                         const float *policy_logits, const float *next_hidden, void *stream);
+/* Injected mode: already-decoded scalars (value, reward dev f64[E]; priors dev f64[E,A]). */
+int mzmcts_expand_backup_injected(mzmcts_engine *engine, const double *value, const double *reward,
+                                  const double *priors, void *stream);
+
+/* Hidden-state pool: slab k (dev f32[E,H]) holds the state of the node expanded by simulation k-1
+ * (slab 0 = roots).  mzmcts_next_slab() is the slab the coming expand_backup will own. */
+float *mzmcts_hidden_slab(mzmcts_engine *engine, int32_t slab);
+int32_t mzmcts_next_slab(const mzmcts_engine *engine);
+int32_t mzmcts_simulations_done(const mzmcts_engine *engine);
+/* Set the host-side simulation counter without touching device state: 0 before a captured
+ * hipGraph of S simulations is replayed for a new move, S after the replay (the launches the graph
+ * replays are not seen by the host-side counter). */
+int mzmcts_set_simulations_done(mzmcts_engine *engine, int32_t n);
+
+/* ---- results ---------------------------------------------------------------------------------
+ * readout: copy the root statistics of all trees to the host (blocking) and advance the host RNG
+ * mirrors by the tie-break words each tree consumed. */
+int mzmcts_readout(mzmcts_engine *engine, const mzmcts_root_stats *out, void *stream);
+/* SelfPlay.select_action (self_play.py:223-246) for every env on its own RNG stream, using the
+ * visit counts of the last readout.  temperature host f64[E] (0 = argmax, +inf = uniform);
+ * action_out host i32[E] (action ids), slot_out optional host i32[E].  Inactive envs give -1. */
+int mzmcts_sample_actions(mzmcts_engine *engine, const double *temperature, int32_t *action_out,
+                          int32_t *slot_out);
+/* GameHistory.store_search_statistics (self_play.py:497-512): child_visits host f64[E,A] over the
+ * full action space, root_values host f64[E]. */
+int mzmcts_search_statistics(mzmcts_engine *engine, double *child_visits, double *root_values);
+
+/* Path of the most recent select per tree (tests, diagnose-style callers): depth host i32[E],
+ * actions host i32[E,S] (-1 padded), tie_counts host i32[E,S].  Blocking. */
+int mzmcts_last_paths(mzmcts_engine *engine, int32_t *depth, int32_t *actions, int32_t *tie_counts,
+                      void *stream);
+/* Make select also record the size of each tie list (needed for tie_counts above; off by default
+ * because it adds a 4-byte store per level).  Allocates: call outside graph capture. */
+int mzmcts_set_debug_ties(mzmcts_engine *engine, int32_t enabled);
+/* Whole tree of one env (Node facade; diagnose_model.py walks root.children recursively):
+ * host arrays over (S+1)*A child records, record (k*A + slot) = child `slot` of expanded node k;
+ * child_node[k*A+slot] = index of that child's own expanded node or -1.  Blocking. */
+int mzmcts_export_tree(mzmcts_engine *engine, int32_t env, int32_t *visits, double *value_sum,
+                       double *prior, double *reward, int32_t *child_node, void *stream);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
+int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */
+/* Bytes of device memory the engine's pools occupy (node blocks, hidden pool, RNG, paths). */
+int64_t mzmcts_device_bytes(const mzmcts_engine *engine);
+
+/* ---- stand-alone host RNG stream (numpy legacy RandomState clone) ----------------------------
+ * The same generator the engine uses per env, exposed for host logic that has no engine
+ * (SelfPlay.select_opponent_action's numpy.random.choice, self_play.py:217) and for CPU tests. */
+typedef struct mzmcts_rng mzmcts_rng;
+mzmcts_rng *mzmcts_rng_create(uint32_t seed);
+void mzmcts_rng_destroy(mzmcts_rng *rng);
+void mzmcts_rng_reseed(mzmcts_rng *rng, uint32_t seed);
+uint32_t mzmcts_rng_next_u32(mzmcts_rng *rng);
+double mzmcts_rng_random_sample(mzmcts_rng *rng);
+uint32_t mzmcts_rng_choice(mzmcts_rng *rng, uint32_t n);            /* numpy.random.choice(range(n)) */
+int32_t mzmcts_rng_choice_p(mzmcts_rng *rng, const double *p, int32_t n); /* choice(n, p=p) */
+void mzmcts_rng_dirichlet(mzmcts_rng *rng, double alpha, int32_t k, double *out);
+void mzmcts_rng_export(const mzmcts_rng *rng, uint32_t *key, int32_t *pos, int32_t *has_gauss,
+                       double *cached_gaussian);
+void mzmcts_rng_import(mzmcts_rng *rng, const uint32_t *key, int32_t pos, int32_t has_gauss,
+                       double cached_gaussian);
+/* select_action on a stand-alone stream: visits host i32[n]; returns the chosen slot. */
+int32_t mzmcts_rng_select_action(mzmcts_rng *rng, const int32_t *visits, int32_t n, double temperature);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZMCTS_H */

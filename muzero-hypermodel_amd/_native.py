@@ -1,0 +1,189 @@
+"""ctypes binding of libmzmcts.so (the C ABI of include/mzmcts.h).
+
+There is NO Python / CPU fallback for the tree kernels: if the library is missing or no HIP device
+is present, loading / engine creation raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+c_u32_p = ctypes.POINTER(ctypes.c_uint32)
+c_f64_p = ctypes.POINTER(ctypes.c_double)
+c_void = ctypes.c_void_p
+
+ABI_VERSION = 1
+ERR_INVALID, ERR_HIP, ERR_EMPTY_LEGAL, ERR_LEGAL_RANGE, ERR_PLAYERS = -1, -2, -3, -4, -5
+
+
+class MzConfig(ctypes.Structure):
+    _fields_ = [("num_envs", ctypes.c_int32), ("num_actions", ctypes.c_int32),
+                ("num_simulations", ctypes.c_int32), ("num_players", ctypes.c_int32),
+                ("support_size", ctypes.c_int32), ("hidden_floats", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("discount", ctypes.c_double), ("pb_c_base", ctypes.c_double),
+                ("pb_c_init", ctypes.c_double), ("root_dirichlet_alpha", ctypes.c_double),
+                ("root_exploration_fraction", ctypes.c_double), ("hidden_pool", c_void)]
+
+
+class MzRootStats(ctypes.Structure):
+    _fields_ = [("visits", c_i32_p), ("child_value_sum", c_f64_p), ("child_prior", c_f64_p),
+                ("child_reward", c_f64_p), ("child_expanded", c_i32_p), ("root_value_sum", c_f64_p),
+                ("root_visits", c_i32_p), ("max_tree_depth", c_i32_p),
+                ("root_predicted_value", c_f64_p), ("min_max", c_f64_p), ("depth_sum", c_i64_p),
+                ("tie_break_words", c_u32_p)]
+
+
+class MzProfile(ctypes.Structure):
+    _fields_ = [("select_ms", ctypes.c_double), ("expand_backup_ms", ctypes.c_double),
+                ("root_ms", ctypes.c_double), ("select_launches", ctypes.c_int64),
+                ("expand_backup_launches", ctypes.c_int64), ("root_launches", ctypes.c_int64),
+                ("select_depth_sum", ctypes.c_int64), ("simulations", ctypes.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/mzmcts.h declares
+PROTOTYPES = {
+    "mzmcts_abi_version": (ctypes.c_int, []),
+    "mzmcts_create": (ctypes.c_int, [ctypes.POINTER(MzConfig), ctypes.POINTER(c_void)]),
+    "mzmcts_destroy": (None, [c_void]),
+    "mzmcts_last_error": (ctypes.c_char_p, [c_void]),
+    "mzmcts_seed": (ctypes.c_int, [c_void, c_u32_p, c_void]),
+    "mzmcts_rng_set_state": (ctypes.c_int, [c_void, ctypes.c_int32, c_u32_p, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_double, c_void]),
+    "mzmcts_rng_get_state": (ctypes.c_int, [c_void, ctypes.c_int32, c_u32_p, c_i32_p, c_i32_p,
+                                            c_f64_p, c_void]),
+    "mzmcts_begin_search": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, ctypes.c_int32,
+                                           c_f64_p, c_void]),
+    "mzmcts_expand_roots": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
+    "mzmcts_expand_roots_injected": (ctypes.c_int, [c_void, c_void, c_void, c_void]),
+    "mzmcts_select": (ctypes.c_int, [c_void, c_void, c_void, c_void]),
+    "mzmcts_expand_backup": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
+    "mzmcts_expand_backup_injected": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void]),
+    "mzmcts_hidden_slab": (c_void, [c_void, ctypes.c_int32]),
+    "mzmcts_next_slab": (ctypes.c_int32, [c_void]),
+    "mzmcts_simulations_done": (ctypes.c_int32, [c_void]),
+    "mzmcts_set_simulations_done": (ctypes.c_int, [c_void, ctypes.c_int32]),
+    "mzmcts_readout": (ctypes.c_int, [c_void, ctypes.POINTER(MzRootStats), c_void]),
+    "mzmcts_sample_actions": (ctypes.c_int, [c_void, c_f64_p, c_i32_p, c_i32_p]),
+    "mzmcts_search_statistics": (ctypes.c_int, [c_void, c_f64_p, c_f64_p]),
+    "mzmcts_last_paths": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_void]),
+    "mzmcts_set_debug_ties": (ctypes.c_int, [c_void, ctypes.c_int32]),
+    "mzmcts_export_tree": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_f64_p, c_f64_p, c_f64_p,
+                                          c_i32_p, c_void]),
+    "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
+    "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
+    "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
+    "mzmcts_rng_create": (c_void, [ctypes.c_uint32]),
+    "mzmcts_rng_destroy": (None, [c_void]),
+    "mzmcts_rng_reseed": (None, [c_void, ctypes.c_uint32]),
+    "mzmcts_rng_next_u32": (ctypes.c_uint32, [c_void]),
+    "mzmcts_rng_random_sample": (ctypes.c_double, [c_void]),
+    "mzmcts_rng_choice": (ctypes.c_uint32, [c_void, ctypes.c_uint32]),
+    "mzmcts_rng_choice_p": (ctypes.c_int32, [c_void, c_f64_p, ctypes.c_int32]),
+    "mzmcts_rng_dirichlet": (None, [c_void, ctypes.c_double, ctypes.c_int32, c_f64_p]),
+    "mzmcts_rng_export": (None, [c_void, c_u32_p, c_i32_p, c_i32_p, c_f64_p]),
+    "mzmcts_rng_import": (None, [c_void, c_u32_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
+    "mzmcts_rng_select_action": (ctypes.c_int32, [c_void, c_i32_p, ctypes.c_int32, ctypes.c_double]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmzmcts.so and bind every prototype.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The MCTS engine has no Python fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here == header / library out of sync
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mzmcts_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("libmzmcts.so ABI version mismatch; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def ptr(arr, typ):
+    """ctypes pointer to a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(typ)
+
+
+def check(lib, engine, rc):
+    """Translate a C-ABI status into the reference's exception types / messages."""
+    if rc == 0:
+        return
+    msg = lib.mzmcts_last_error(engine)
+    msg = msg.decode() if msg else f"mzmcts error {rc}"
+    if rc in (ERR_EMPTY_LEGAL, ERR_LEGAL_RANGE):
+        raise AssertionError(msg)
+    if rc == ERR_PLAYERS:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+class HostRng:
+    """numpy legacy RandomState clone on the host (stand-alone stream of the C library)."""
+
+    def __init__(self, seed=0):
+        self._lib = load()
+        self._h = self._lib.mzmcts_rng_create(int(seed) & 0xFFFFFFFF)
+
+    def __del__(self):
+        try:
+            self._lib.mzmcts_rng_destroy(self._h)
+        except Exception:
+            pass
+
+    def seed(self, seed):
+        self._lib.mzmcts_rng_reseed(self._h, int(seed) & 0xFFFFFFFF)
+
+    def next_u32(self):
+        return self._lib.mzmcts_rng_next_u32(self._h)
+
+    def random_sample(self):
+        return self._lib.mzmcts_rng_random_sample(self._h)
+
+    def choice(self, n):
+        return self._lib.mzmcts_rng_choice(self._h, n)
+
+    def choice_p(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        return self._lib.mzmcts_rng_choice_p(self._h, ptr(p, c_f64_p), len(p))
+
+    def dirichlet(self, alpha, k):
+        out = np.zeros(k, dtype=np.float64)
+        self._lib.mzmcts_rng_dirichlet(self._h, float(alpha), k, ptr(out, c_f64_p))
+        return out
+
+    def select_action(self, visits, temperature):
+        v = np.ascontiguousarray(visits, dtype=np.int32)
+        return self._lib.mzmcts_rng_select_action(self._h, ptr(v, c_i32_p), len(v), float(temperature))
+
+    def get_state(self):
+        key = np.zeros(624, dtype=np.uint32)
+        pos, hg, g = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        self._lib.mzmcts_rng_export(self._h, ptr(key, c_u32_p), ctypes.byref(pos), ctypes.byref(hg),
+                                    ctypes.byref(g))
+        return ("MT19937", key, pos.value, hg.value, g.value)
+
+    def set_state(self, state):
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        self._lib.mzmcts_rng_import(self._h, ptr(key, c_u32_p), int(state[2]), int(state[3]),
+                                    float(state[4]))

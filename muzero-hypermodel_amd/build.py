@@ -1,0 +1,51 @@
+"""Builds libmzmcts.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+.so is git-ignored but travels to the GPU box with the working tree.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
+SOURCES = ["mcts_kernels.hip", "mzmcts_capi.hip"]
+HEADERS = ["np_legacy_rng.h", "tree_layout.h", os.path.join("..", "..", "include", "mzmcts.h")]
+
+# -ffp-contract=off is part of the numerical contract: the fp64 UCB / backup arithmetic must not be
+# fused into FMAs or it stops being bit-identical to the reference's Python floats.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-variable"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X MCTS engine cannot be built without ROCm")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    """Compile csrc/*.hip into muzero-hypermodel_amd/libmzmcts.so; returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,768 @@
+// mzmcts_capi.hip -- host side of libmzmcts.so: the C ABI declared in include/mzmcts.h.
+//
+// Owns the device pools, the per-tree RNG mirrors and the staging buffers; launches the kernels of
+// mcts_kernels.hip.  Launch functions do no allocation and no synchronisation (hipGraph-capturable);
+// everything blocking says so in the header.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mzmcts.h"
+#include "np_legacy_rng.h"
+#include "tree_layout.h"
+
+namespace mz {
+hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream);
+hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
+                               const float* policy_logits, const float* root_hidden, const double* inj_reward,
+                               const double* inj_priors, const double* noise, const uint32_t* rng_skip,
+                               bool injected, hipStream_t stream);
+hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
+                                const float* policy_logits, const double* inj_value, const double* inj_reward,
+                                const double* inj_priors, bool injected, hipStream_t stream);
+hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t stream);
+hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
+}  // namespace mz
+
+namespace {
+thread_local std::string g_create_error;
+
+enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfKinds = 3 };
+struct EventPair {
+    hipEvent_t begin, end;
+    int kind;
+};
+}  // namespace
+
+struct mzmcts_engine {
+    mzmcts_config cfg{};
+    mz::TreeParams p{};
+    std::string error;
+    int sim = 0;            // simulations launched since expand_roots
+    bool roots_ready = false;
+    bool search_begun = false;
+    bool have_readout = false;
+    bool owns_hidden = false;
+    int64_t device_bytes = 0;
+
+    // device staging for the per-move host inputs
+    double* d_noise = nullptr;
+    uint32_t* d_skip = nullptr;
+    uint32_t* d_seeds = nullptr;
+    bool noise_this_search = false;
+
+    // pinned host staging
+    int32_t* h_legal = nullptr;      // [E][A]
+    int32_t* h_nlegal = nullptr;     // [E]
+    int32_t* h_to_play = nullptr;    // [E]
+    double* h_noise = nullptr;       // [E][A]
+    uint32_t* h_skip = nullptr;      // [E]
+    uint8_t* h_slab0 = nullptr;      // [E][block_stride]
+    double* h_root_value_sum = nullptr;
+    float* h_root_predicted = nullptr;
+    int32_t* h_max_depth = nullptr;
+    int64_t* h_depth_sum = nullptr;
+    uint32_t* h_tie_words = nullptr;
+    mz::MinMax* h_min_max = nullptr;
+    int32_t* h_error_flag = nullptr;
+
+    // host RNG mirrors; lag[e] = words the host stream is ahead of the device copy
+    std::vector<mz::HostStream> streams;
+    std::vector<uint32_t> lag;
+
+    // cache of the last readout (sample_actions / search_statistics)
+    std::vector<int32_t> last_visits;       // [E][A] per slot
+    std::vector<double> last_root_value_sum;
+    std::vector<int32_t> last_root_visits;
+
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    mzmcts_profile prof{};
+
+    std::vector<void*> device_allocs;
+    std::vector<void*> pinned_allocs;
+};
+
+namespace {
+
+int fail(mzmcts_engine* eng, int code, const std::string& msg) {
+    if (eng) eng->error = msg;
+    g_create_error = msg;
+    return code;
+}
+
+int hip_fail(mzmcts_engine* eng, hipError_t err, const char* what) {
+    return fail(eng, MZMCTS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+#define MZ_HIP(eng, call)                                         \
+    do {                                                          \
+        hipError_t err__ = (call);                                \
+        if (err__ != hipSuccess) return hip_fail(eng, err__, #call); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mzmcts_engine* eng, T** out, size_t count, bool zero = true) {
+    void* ptr = nullptr;
+    const size_t bytes = count * sizeof(T);
+    MZ_HIP(eng, hipMalloc(&ptr, bytes ? bytes : 16));
+    if (zero) MZ_HIP(eng, hipMemset(ptr, 0, bytes ? bytes : 16));
+    eng->device_allocs.push_back(ptr);
+    eng->device_bytes += static_cast<int64_t>(bytes);
+    *out = static_cast<T*>(ptr);
+    return 0;
+}
+
+template <typename T>
+int pinned_alloc(mzmcts_engine* eng, T** out, size_t count) {
+    void* ptr = nullptr;
+    const size_t bytes = count * sizeof(T);
+    MZ_HIP(eng, hipHostMalloc(&ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    std::memset(ptr, 0, bytes ? bytes : 16);
+    eng->pinned_allocs.push_back(ptr);
+    *out = static_cast<T*>(ptr);
+    return 0;
+}
+
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+    return st != hipStreamCaptureStatusNone;
+}
+
+// bracket a launch with HIP events on the launch stream (profiling mode, never while capturing)
+struct ProfScope {
+    mzmcts_engine* eng;
+    hipStream_t stream;
+    EventPair* pair = nullptr;
+    ProfScope(mzmcts_engine* e, hipStream_t s, int kind) : eng(e), stream(s) {
+        if (!eng->profiling || stream_is_capturing(s)) return;
+        if (eng->events_used == eng->events.size()) {
+            EventPair np{};
+            if (hipEventCreate(&np.begin) != hipSuccess || hipEventCreate(&np.end) != hipSuccess) return;
+            eng->events.push_back(np);
+        }
+        pair = &eng->events[eng->events_used++];
+        pair->kind = kind;
+        (void)hipEventRecord(pair->begin, stream);
+    }
+    ~ProfScope() {
+        if (pair) (void)hipEventRecord(pair->end, stream);
+    }
+};
+
+void parallel_for(int n, int max_threads, const std::function<void(int, int)>& body) {
+    int hw = static_cast<int>(std::thread::hardware_concurrency());
+    if (hw <= 0) hw = 1;
+    int threads = std::min(std::min(hw, max_threads), std::max(1, n / 512));
+    if (threads <= 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        const int lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back([=, &body] { body(lo, hi); });
+    }
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+extern "C" {
+
+int mzmcts_abi_version(void) { return MZMCTS_ABI_VERSION; }
+
+const char* mzmcts_last_error(const mzmcts_engine* engine) {
+    return engine ? engine->error.c_str() : g_create_error.c_str();
+}
+
+int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
+    if (!c || !out) return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: null argument");
+    *out = nullptr;
+    if (c->num_envs <= 0 || c->num_actions <= 0 || c->num_simulations <= 0 || c->support_size < 0 ||
+        c->hidden_floats < 0)
+        return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: sizes must be positive");
+    if (c->num_players < 1 || c->num_players > 2)
+        return fail(nullptr, MZMCTS_ERR_PLAYERS, "More than two player mode not implemented.");
+    if (c->num_actions > 256)
+        return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: at most 256 actions are supported");
+    if (c->num_simulations > 32767)
+        return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: at most 32767 simulations are supported");
+
+    int n_dev = 0;
+    hipError_t err = hipGetDeviceCount(&n_dev);
+    if (err != hipSuccess || n_dev <= 0)
+        return fail(nullptr, MZMCTS_ERR_HIP,
+                    std::string("mzmcts_create: no HIP device available (") +
+                        (err != hipSuccess ? hipGetErrorString(err) : "device count 0") +
+                        "); the MCTS engine has no CPU fallback");
+    if (c->device < 0 || c->device >= n_dev) return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: bad device ordinal");
+    err = hipSetDevice(c->device);
+    if (err != hipSuccess) return hip_fail(nullptr, err, "hipSetDevice");
+
+    auto* eng = new mzmcts_engine();
+    eng->cfg = *c;
+    const int E = c->num_envs, A = c->num_actions, S = c->num_simulations, H = c->hidden_floats;
+    mz::TreeParams& p = eng->p;
+    p.E = E;
+    p.A = A;
+    p.S = S;
+    p.P = c->num_players;
+    p.support = c->support_size;
+    p.F = 2 * c->support_size + 1;
+    p.H = H;
+    p.chunks = A > 64 ? (A + 63) / 64 : 1;
+    p.links_offset = 16u * static_cast<uint32_t>(A);
+    p.block_stride = mz::round_up(32u * static_cast<uint32_t>(A), 64u);
+    p.discount = c->discount;
+    p.noise_frac = c->root_exploration_fraction;
+
+    int rc = 0;
+    auto cleanup_on = [&](int code) {
+        if (code != 0) {
+            g_create_error = eng->error;
+            mzmcts_destroy(eng);
+        }
+        return code;
+    };
+    const size_t K = static_cast<size_t>(S) + 1;
+    if ((rc = dev_alloc(eng, &p.blocks, K * E * p.block_stride))) return cleanup_on(rc);
+    if (c->hidden_pool) {
+        p.hidden = static_cast<float*>(c->hidden_pool);
+    } else {
+        if ((rc = dev_alloc(eng, &p.hidden, K * E * static_cast<size_t>(H), false))) return cleanup_on(rc);
+        eng->owns_hidden = true;
+    }
+    if ((rc = dev_alloc(eng, &p.path, static_cast<size_t>(S) * E))) return cleanup_on(rc);
+    p.path_ties = nullptr;
+    if ((rc = dev_alloc(eng, &p.path_len, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.leaf_parent, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.min_max, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_value_sum, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_reward, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_predicted, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_children, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_to_play, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.root_action, static_cast<size_t>(E) * A))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.max_depth, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.depth_sum, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.tie_words, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.mt_key, static_cast<size_t>(E) * mz::kMtN))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.mt_pos, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.error_flag, 4))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &eng->d_noise, static_cast<size_t>(E) * A))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &eng->d_skip, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &eng->d_seeds, E))) return cleanup_on(rc);
+
+    // pb_c tables: host libm, the same log/sqrt Python's math module calls (self_play.py:385-391)
+    {
+        std::vector<double> tab(2 * K);
+        for (size_t n = 0; n < K; ++n) {
+            tab[n] = std::log((static_cast<double>(n) + c->pb_c_base + 1) / c->pb_c_base) + c->pb_c_init;
+            tab[K + n] = std::sqrt(static_cast<double>(n));
+        }
+        double* d_tab = nullptr;
+        if ((rc = dev_alloc(eng, &d_tab, 2 * K))) return cleanup_on(rc);
+        err = hipMemcpy(d_tab, tab.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice);
+        if (err != hipSuccess) return cleanup_on(hip_fail(eng, err, "hipMemcpy(pb_c table)"));
+        p.pbc_log = d_tab;
+        p.pbc_sqrt = d_tab + K;
+    }
+
+    if ((rc = pinned_alloc(eng, &eng->h_legal, static_cast<size_t>(E) * A))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_nlegal, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_to_play, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_noise, static_cast<size_t>(E) * A))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_skip, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_slab0, static_cast<size_t>(E) * p.block_stride))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_root_value_sum, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_root_predicted, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_max_depth, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_depth_sum, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_tie_words, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_min_max, E))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_error_flag, 4))) return cleanup_on(rc);
+
+    eng->streams.resize(E);
+    eng->lag.assign(E, 0u);
+    eng->last_visits.assign(static_cast<size_t>(E) * A, 0);
+    eng->last_root_value_sum.assign(E, 0.0);
+    eng->last_root_visits.assign(E, 0);
+    // default seeding: stream e == numpy.random.seed(e)
+    std::vector<uint32_t> seeds(E);
+    for (int e = 0; e < E; ++e) seeds[e] = static_cast<uint32_t>(e);
+    *out = eng;
+    rc = mzmcts_seed(eng, seeds.data(), nullptr);
+    if (rc != 0) {
+        *out = nullptr;
+        return cleanup_on(rc);
+    }
+    return MZMCTS_OK;
+}
+
+void mzmcts_destroy(mzmcts_engine* eng) {
+    if (!eng) return;
+    (void)hipSetDevice(eng->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& ev : eng->events) {
+        (void)hipEventDestroy(ev.begin);
+        (void)hipEventDestroy(ev.end);
+    }
+    for (void* ptr : eng->device_allocs) (void)hipFree(ptr);
+    for (void* ptr : eng->pinned_allocs) (void)hipHostFree(ptr);
+    delete eng;
+}
+
+int mzmcts_seed(mzmcts_engine* eng, const uint32_t* seeds, void* stream_) {
+    if (!eng || !seeds) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_seed: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int E = eng->p.E;
+    parallel_for(E, 16, [&](int lo, int hi) {
+        for (int e = lo; e < hi; ++e) eng->streams[e].seed(seeds[e]);
+    });
+    std::fill(eng->lag.begin(), eng->lag.end(), 0u);
+    MZ_HIP(eng, hipMemcpyAsync(eng->d_seeds, seeds, sizeof(uint32_t) * E, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, mz::launch_seed_streams(eng->p.mt_key, eng->p.mt_pos, eng->d_seeds, E, stream));
+    MZ_HIP(eng, hipStreamSynchronize(stream));
+    return MZMCTS_OK;
+}
+
+int mzmcts_rng_set_state(mzmcts_engine* eng, int32_t env, const uint32_t* key, int32_t pos, int32_t has_gauss,
+                         double cached, void* stream_) {
+    if (!eng || !key || env < 0 || env >= eng->p.E || pos < 0 || pos > mz::kMtN)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_rng_set_state: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    mz::HostStream& s = eng->streams[env];
+    std::memcpy(s.key, key, sizeof(s.key));
+    s.pos = pos;
+    s.has_gauss = has_gauss;
+    s.gauss = cached;
+    eng->lag[env] = 0;
+    MZ_HIP(eng, hipMemcpyAsync(eng->p.mt_key + static_cast<size_t>(env) * mz::kMtN, s.key, sizeof(s.key),
+                               hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->p.mt_pos + env, &s.pos, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipStreamSynchronize(stream));
+    return MZMCTS_OK;
+}
+
+int mzmcts_rng_get_state(mzmcts_engine* eng, int32_t env, uint32_t* key, int32_t* pos, int32_t* has_gauss,
+                         double* cached, void* stream_) {
+    if (!eng || !key || !pos || env < 0 || env >= eng->p.E)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_rng_get_state: bad argument");
+    (void)stream_;
+    const mz::HostStream& s = eng->streams[env];  // the host mirror is authoritative between calls
+    std::memcpy(key, s.key, sizeof(s.key));
+    *pos = s.pos;
+    if (has_gauss) *has_gauss = s.has_gauss;
+    if (cached) *cached = s.gauss;
+    return MZMCTS_OK;
+}
+
+int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t* num_legal, const int32_t* to_play,
+                        int32_t add_noise, double* noise_out, void* stream_) {
+    if (!eng || !legal || !num_legal || !to_play)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_begin_search: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int E = eng->p.E, A = eng->p.A;
+    // plugin contract (self_play.py:297-302)
+    for (int e = 0; e < E; ++e) {
+        const int n = num_legal[e];
+        if (n < 0 || n > A)
+            return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
+        for (int i = 0; i < n; ++i) {
+            const int a = legal[static_cast<size_t>(e) * A + i];
+            if (a < 0 || a >= A)
+                return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
+        }
+    }
+    std::memcpy(eng->h_legal, legal, sizeof(int32_t) * static_cast<size_t>(E) * A);
+    std::memcpy(eng->h_nlegal, num_legal, sizeof(int32_t) * E);
+    std::memcpy(eng->h_to_play, to_play, sizeof(int32_t) * E);
+    const double alpha = eng->cfg.root_dirichlet_alpha;
+    parallel_for(E, 16, [&](int lo, int hi) {
+        for (int e = lo; e < hi; ++e) {
+            const int n = eng->h_nlegal[e];
+            double* row = eng->h_noise + static_cast<size_t>(e) * A;
+            for (int i = 0; i < A; ++i) row[i] = 0.0;
+            if (n == 0) {
+                eng->h_skip[e] = 0;  // inactive: the stream is left alone, pending lag is kept
+                continue;
+            }
+            if (add_noise) {
+                mz::HostStream& s = eng->streams[e];
+                const uint64_t before = s.words;
+                s.dirichlet(alpha, n, row);
+                eng->lag[e] += static_cast<uint32_t>(s.words - before);
+            }
+            eng->h_skip[e] = eng->lag[e];
+            eng->lag[e] = 0;
+        }
+    });
+    if (noise_out) std::memcpy(noise_out, eng->h_noise, sizeof(double) * static_cast<size_t>(E) * A);
+    eng->noise_this_search = add_noise != 0;
+    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_action, eng->h_legal, sizeof(int32_t) * static_cast<size_t>(E) * A,
+                               hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_children, eng->h_nlegal, sizeof(int32_t) * E, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_to_play, eng->h_to_play, sizeof(int32_t) * E, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->d_skip, eng->h_skip, sizeof(uint32_t) * E, hipMemcpyHostToDevice, stream));
+    if (add_noise)
+        MZ_HIP(eng, hipMemcpyAsync(eng->d_noise, eng->h_noise, sizeof(double) * static_cast<size_t>(E) * A,
+                                   hipMemcpyHostToDevice, stream));
+    eng->search_begun = true;
+    eng->roots_ready = false;
+    eng->have_readout = false;
+    eng->sim = 0;
+    return MZMCTS_OK;
+}
+
+static int expand_roots_common(mzmcts_engine* eng, const float* value_logits, const float* reward_logits,
+                               const float* policy_logits, const float* root_hidden, const double* inj_reward,
+                               const double* inj_priors, bool injected, hipStream_t stream) {
+    if (!eng->search_begun) return fail(eng, MZMCTS_ERR_INVALID, "expand_roots called before begin_search");
+    {
+        ProfScope scope(eng, stream, kProfRoot);
+        MZ_HIP(eng, mz::launch_expand_roots(eng->p, value_logits, reward_logits, policy_logits, root_hidden, inj_reward,
+                                            inj_priors, eng->noise_this_search ? eng->d_noise : nullptr, eng->d_skip,
+                                            injected, stream));
+    }
+    eng->roots_ready = true;
+    eng->sim = 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_expand_roots(mzmcts_engine* eng, const float* value_logits, const float* reward_logits,
+                        const float* policy_logits, const float* root_hidden, void* stream) {
+    if (!eng || !value_logits || !policy_logits)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_roots: null argument");
+    return expand_roots_common(eng, value_logits, reward_logits, policy_logits, root_hidden, nullptr, nullptr, false,
+                               static_cast<hipStream_t>(stream));
+}
+
+int mzmcts_expand_roots_injected(mzmcts_engine* eng, const double* root_reward, const double* root_priors, void* stream) {
+    if (!eng || !root_reward || !root_priors)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_roots_injected: null argument");
+    return expand_roots_common(eng, nullptr, nullptr, nullptr, nullptr, root_reward, root_priors, true,
+                               static_cast<hipStream_t>(stream));
+}
+
+int mzmcts_select(mzmcts_engine* eng, float* parent_hidden_out, int64_t* action_out, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (!eng->roots_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select called before expand_roots");
+    if (eng->sim >= eng->p.S) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select: all simulations already ran");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope scope(eng, stream, kProfSelect);
+    MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream));
+    return MZMCTS_OK;
+}
+
+int mzmcts_expand_backup(mzmcts_engine* eng, const float* value_logits, const float* reward_logits,
+                         const float* policy_logits, const float* next_hidden, void* stream_) {
+    if (!eng || !value_logits || !reward_logits || !policy_logits)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup: null argument");
+    if (!eng->roots_ready || eng->sim >= eng->p.S)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup: no simulation in flight");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (next_hidden && eng->p.H > 0) {
+        float* slab = eng->p.hidden + (static_cast<size_t>(eng->sim) + 1) * eng->p.E * eng->p.H;
+        MZ_HIP(eng, mz::launch_copy_slab(next_hidden, slab, static_cast<size_t>(eng->p.E) * eng->p.H, stream));
+    }
+    {
+        ProfScope scope(eng, stream, kProfBackup);
+        MZ_HIP(eng, mz::launch_expand_backup(eng->p, eng->sim, value_logits, reward_logits, policy_logits, nullptr,
+                                             nullptr, nullptr, false, stream));
+    }
+    eng->sim += 1;
+    return MZMCTS_OK;
+}
+
+int mzmcts_expand_backup_injected(mzmcts_engine* eng, const double* value, const double* reward, const double* priors,
+                                  void* stream_) {
+    if (!eng || !value || !reward || !priors)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_injected: null argument");
+    if (!eng->roots_ready || eng->sim >= eng->p.S)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_injected: no simulation in flight");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    {
+        ProfScope scope(eng, stream, kProfBackup);
+        MZ_HIP(eng, mz::launch_expand_backup(eng->p, eng->sim, nullptr, nullptr, nullptr, value, reward, priors, true,
+                                             stream));
+    }
+    eng->sim += 1;
+    return MZMCTS_OK;
+}
+
+float* mzmcts_hidden_slab(mzmcts_engine* eng, int32_t slab) {
+    if (!eng || slab < 0 || slab > eng->p.S || eng->p.H == 0) return nullptr;
+    return eng->p.hidden + static_cast<size_t>(slab) * eng->p.E * eng->p.H;
+}
+
+int32_t mzmcts_next_slab(const mzmcts_engine* eng) { return eng ? eng->sim + 1 : -1; }
+int32_t mzmcts_simulations_done(const mzmcts_engine* eng) { return eng ? eng->sim : -1; }
+
+int mzmcts_set_simulations_done(mzmcts_engine* eng, int32_t n) {
+    if (!eng || n < 0 || n > eng->p.S) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_simulations_done: out of range");
+    eng->sim = n;
+    return MZMCTS_OK;
+}
+
+int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (!eng->roots_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_readout called before expand_roots");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const mz::TreeParams& p = eng->p;
+    const int E = p.E, A = p.A;
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(E) * p.block_stride, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_root_value_sum, p.root_value_sum, sizeof(double) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_root_predicted, p.root_predicted, sizeof(float) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_max_depth, p.max_depth, sizeof(int32_t) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_depth_sum, p.depth_sum, sizeof(int64_t) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_tie_words, p.tie_words, sizeof(uint32_t) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_min_max, p.min_max, sizeof(mz::MinMax) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipStreamSynchronize(stream));
+    if (eng->h_error_flag[0] != 0)
+        return fail(eng, MZMCTS_ERR_INVALID, "device error flag set: a UCB score was NaN (no maximum to select)");
+
+    const int sims = eng->sim;
+    int64_t depth_total = 0, active = 0;
+    for (int e = 0; e < E; ++e) {
+        const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.block_stride;
+        const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
+        const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
+        const int n = eng->h_nlegal[e];
+        const bool is_active = n > 0;
+        for (int i = 0; i < A; ++i) {
+            const size_t o = static_cast<size_t>(e) * A + i;
+            const bool live = i < n;
+            eng->last_visits[o] = live ? lk[i].visits : 0;
+            if (out) {
+                if (out->visits) out->visits[o] = live ? lk[i].visits : 0;
+                if (out->child_value_sum) out->child_value_sum[o] = live ? st[i].value_sum : 0.0;
+                if (out->child_prior) out->child_prior[o] = live ? st[i].prior : 0.0;
+                if (out->child_reward) out->child_reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
+                if (out->child_expanded) out->child_expanded[o] = (live && lk[i].child_node >= 0) ? 1 : 0;
+            }
+        }
+        eng->last_root_value_sum[e] = is_active ? eng->h_root_value_sum[e] : 0.0;
+        eng->last_root_visits[e] = is_active ? sims : 0;
+        if (is_active) {
+            // the tie-breaks ran on the device copy of the stream: bring the host mirror level
+            eng->streams[e].skip(eng->h_tie_words[e]);
+            depth_total += eng->h_depth_sum[e];
+            ++active;
+        }
+        if (out) {
+            if (out->root_value_sum) out->root_value_sum[e] = eng->last_root_value_sum[e];
+            if (out->root_visits) out->root_visits[e] = eng->last_root_visits[e];
+            if (out->max_tree_depth) out->max_tree_depth[e] = is_active ? eng->h_max_depth[e] : 0;
+            if (out->root_predicted_value) out->root_predicted_value[e] = static_cast<double>(eng->h_root_predicted[e]);
+            if (out->min_max) {
+                out->min_max[2 * e] = eng->h_min_max[e].minimum;
+                out->min_max[2 * e + 1] = eng->h_min_max[e].maximum;
+            }
+            if (out->depth_sum) out->depth_sum[e] = is_active ? eng->h_depth_sum[e] : 0;
+            if (out->tie_break_words) out->tie_break_words[e] = is_active ? eng->h_tie_words[e] : 0u;
+        }
+    }
+    eng->prof.select_depth_sum += depth_total;
+    eng->prof.simulations += active * sims;
+    // a tree's tie words must not be applied twice if readout is called again
+    MZ_HIP(eng, hipMemsetAsync(p.tie_words, 0, sizeof(uint32_t) * E, stream));
+    MZ_HIP(eng, hipMemsetAsync(p.depth_sum, 0, sizeof(int64_t) * E, stream));
+    eng->have_readout = true;
+    return MZMCTS_OK;
+}
+
+int mzmcts_sample_actions(mzmcts_engine* eng, const double* temperature, int32_t* action_out, int32_t* slot_out) {
+    if (!eng || !temperature || !action_out)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_sample_actions: null argument");
+    if (!eng->have_readout) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_sample_actions called before readout");
+    const int E = eng->p.E, A = eng->p.A;
+    parallel_for(E, 16, [&](int lo, int hi) {
+        for (int e = lo; e < hi; ++e) {
+            const int n = eng->h_nlegal[e];
+            if (n == 0) {
+                action_out[e] = -1;
+                if (slot_out) slot_out[e] = -1;
+                continue;
+            }
+            mz::HostStream& s = eng->streams[e];
+            const uint64_t before = s.words;
+            const int slot = s.select_action(eng->last_visits.data() + static_cast<size_t>(e) * A, n, temperature[e]);
+            eng->lag[e] += static_cast<uint32_t>(s.words - before);
+            action_out[e] = eng->h_legal[static_cast<size_t>(e) * A + slot];
+            if (slot_out) slot_out[e] = slot;
+        }
+    });
+    return MZMCTS_OK;
+}
+
+int mzmcts_search_statistics(mzmcts_engine* eng, double* child_visits, double* root_values) {
+    if (!eng || !child_visits || !root_values)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_statistics: null argument");
+    if (!eng->have_readout) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_statistics called before readout");
+    const int E = eng->p.E, A = eng->p.A;
+    for (int e = 0; e < E; ++e) {
+        double* row = child_visits + static_cast<size_t>(e) * A;
+        for (int a = 0; a < A; ++a) row[a] = 0.0;
+        const int n = eng->h_nlegal[e];
+        int total = 0;
+        for (int i = 0; i < n; ++i) total += eng->last_visits[static_cast<size_t>(e) * A + i];
+        for (int i = 0; i < n; ++i)
+            row[eng->h_legal[static_cast<size_t>(e) * A + i]] =
+                static_cast<double>(eng->last_visits[static_cast<size_t>(e) * A + i]) / total;
+        const int rv = eng->last_root_visits[e];
+        root_values[e] = rv == 0 ? 0.0 : eng->last_root_value_sum[e] / rv;
+    }
+    return MZMCTS_OK;
+}
+
+int mzmcts_set_debug_ties(mzmcts_engine* eng, int32_t enabled) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (enabled && !eng->p.path_ties) {
+        int rc = dev_alloc(eng, &eng->p.path_ties, static_cast<size_t>(eng->p.S) * eng->p.E);
+        if (rc) return rc;
+    }
+    return MZMCTS_OK;
+}
+
+int mzmcts_last_paths(mzmcts_engine* eng, int32_t* depth, int32_t* actions, int32_t* tie_counts, void* stream_) {
+    if (!eng || !depth) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_last_paths: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const mz::TreeParams& p = eng->p;
+    const int E = p.E, S = p.S, A = p.A;
+    std::vector<int32_t> path(static_cast<size_t>(S) * E), ties;
+    MZ_HIP(eng, hipMemcpyAsync(depth, p.path_len, sizeof(int32_t) * E, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(path.data(), p.path, sizeof(int32_t) * path.size(), hipMemcpyDeviceToHost, stream));
+    if (tie_counts && p.path_ties) {
+        ties.resize(path.size());
+        MZ_HIP(eng, hipMemcpyAsync(ties.data(), p.path_ties, sizeof(int32_t) * ties.size(), hipMemcpyDeviceToHost, stream));
+    }
+    MZ_HIP(eng, hipStreamSynchronize(stream));
+    for (int e = 0; e < E; ++e) {
+        for (int d = 0; d < S; ++d) {
+            const size_t o = static_cast<size_t>(e) * S + d;
+            if (d < depth[e]) {
+                const int slot = path[static_cast<size_t>(d) * E + e] & 0xffff;
+                if (actions) actions[o] = (d == 0) ? eng->h_legal[static_cast<size_t>(e) * A + slot] : slot;
+                if (tie_counts) tie_counts[o] = ties.empty() ? -1 : ties[static_cast<size_t>(d) * E + e];
+            } else {
+                if (actions) actions[o] = -1;
+                if (tie_counts) tie_counts[o] = 0;
+            }
+        }
+    }
+    return MZMCTS_OK;
+}
+
+int mzmcts_export_tree(mzmcts_engine* eng, int32_t env, int32_t* visits, double* value_sum, double* prior,
+                       double* reward, int32_t* child_node, void* stream_) {
+    if (!eng || env < 0 || env >= eng->p.E) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_export_tree: bad env");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const mz::TreeParams& p = eng->p;
+    const int K = p.S + 1, A = p.A;
+    std::vector<uint8_t> buf(static_cast<size_t>(K) * p.block_stride);
+    MZ_HIP(eng, hipMemcpy2DAsync(buf.data(), p.block_stride, p.blocks + static_cast<size_t>(env) * p.block_stride,
+                                 static_cast<size_t>(p.E) * p.block_stride, p.block_stride, K, hipMemcpyDeviceToHost,
+                                 stream));
+    MZ_HIP(eng, hipStreamSynchronize(stream));
+    const int n_root = eng->h_nlegal[env];
+    for (int k = 0; k < K; ++k) {
+        const uint8_t* blk = buf.data() + static_cast<size_t>(k) * p.block_stride;
+        const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
+        const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
+        const bool written = k <= eng->sim;
+        for (int i = 0; i < A; ++i) {
+            const size_t o = static_cast<size_t>(k) * A + i;
+            const bool live = written && (k > 0 || i < n_root);
+            if (visits) visits[o] = live ? lk[i].visits : 0;
+            if (value_sum) value_sum[o] = live ? st[i].value_sum : 0.0;
+            if (prior) prior[o] = live ? st[i].prior : 0.0;
+            if (reward) reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
+            if (child_node) child_node[o] = live ? lk[i].child_node : -1;
+        }
+    }
+    return MZMCTS_OK;
+}
+
+int mzmcts_set_profiling(mzmcts_engine* eng, int32_t enabled) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    eng->profiling = enabled != 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_get_profile(mzmcts_engine* eng, mzmcts_profile* out, int32_t reset) {
+    if (!eng || !out) return MZMCTS_ERR_INVALID;
+    for (size_t i = 0; i < eng->events_used; ++i) {
+        EventPair& ev = eng->events[i];
+        MZ_HIP(eng, hipEventSynchronize(ev.end));
+        float ms = 0.f;
+        MZ_HIP(eng, hipEventElapsedTime(&ms, ev.begin, ev.end));
+        switch (ev.kind) {
+            case kProfSelect:
+                eng->prof.select_ms += ms;
+                eng->prof.select_launches += 1;
+                break;
+            case kProfBackup:
+                eng->prof.expand_backup_ms += ms;
+                eng->prof.expand_backup_launches += 1;
+                break;
+            default:
+                eng->prof.root_ms += ms;
+                eng->prof.root_launches += 1;
+                break;
+        }
+    }
+    eng->events_used = 0;
+    *out = eng->prof;
+    if (reset) eng->prof = mzmcts_profile{};
+    return MZMCTS_OK;
+}
+
+int64_t mzmcts_device_bytes(const mzmcts_engine* eng) { return eng ? eng->device_bytes : 0; }
+
+// ---- stand-alone host streams ----------------------------------------------------------------------
+struct mzmcts_rng {
+    mz::HostStream s;
+};
+
+mzmcts_rng* mzmcts_rng_create(uint32_t seed) {
+    auto* r = new mzmcts_rng();
+    r->s.seed(seed);
+    return r;
+}
+void mzmcts_rng_destroy(mzmcts_rng* r) { delete r; }
+void mzmcts_rng_reseed(mzmcts_rng* r, uint32_t seed) { r->s.seed(seed); }
+uint32_t mzmcts_rng_next_u32(mzmcts_rng* r) { return r->s.u32(); }
+double mzmcts_rng_random_sample(mzmcts_rng* r) { return r->s.uniform(); }
+uint32_t mzmcts_rng_choice(mzmcts_rng* r, uint32_t n) { return r->s.below(n); }
+int32_t mzmcts_rng_choice_p(mzmcts_rng* r, const double* p, int32_t n) { return r->s.choice_p(p, n); }
+void mzmcts_rng_dirichlet(mzmcts_rng* r, double alpha, int32_t k, double* out) { r->s.dirichlet(alpha, k, out); }
+void mzmcts_rng_export(const mzmcts_rng* r, uint32_t* key, int32_t* pos, int32_t* has_gauss, double* cached) {
+    std::memcpy(key, r->s.key, sizeof(r->s.key));
+    *pos = r->s.pos;
+    *has_gauss = r->s.has_gauss;
+    *cached = r->s.gauss;
+}
+void mzmcts_rng_import(mzmcts_rng* r, const uint32_t* key, int32_t pos, int32_t has_gauss, double cached) {
+    std::memcpy(r->s.key, key, sizeof(r->s.key));
+    r->s.pos = pos;
+    r->s.has_gauss = has_gauss;
+    r->s.gauss = cached;
+}
+int32_t mzmcts_rng_select_action(mzmcts_rng* r, const int32_t* visits, int32_t n, double temperature) {
+    return r->s.select_action(visits, n, temperature);
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// np_legacy_rng.h -- numpy legacy RandomState streams, one per search tree.
+//
+// The reference draws all of its randomness from numpy's global legacy generator
+// (self_play.py:22 seed; :474 dirichlet; :372 tie-break choice; :237,:244 action sampling; :217
+// random opponent).  To give tree e the exact behaviour of reference worker `config.seed + e`
+// each tree owns a clone of that generator:
+//   * the MT19937 core (seeding, twist, tempering) and the bounded-integer draw used by
+//     `numpy.random.choice(list)` are integer-only and run on BOTH host and device (the select
+//     kernel breaks UCB ties on-device);
+//   * everything that needs libm transcendentals (gamma / Dirichlet) or visit-count powers
+//     (select_action) runs on the host against the same glibc libm numpy itself calls, on a host
+//     mirror of the stream that is kept in step with the device copy by word counts.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#define MZ_HD __host__ __device__
+#else
+#define MZ_HD
+#endif
+
+namespace mz {
+
+constexpr int kMtN = 624;
+constexpr int kMtM = 397;
+
+// ---- MT19937 core over caller-provided storage (key[624] + pos) -------------------------------
+MZ_HD inline void mt_seed(uint32_t* key, int32_t* pos, uint32_t seed) {
+    // numpy.random.seed(int) -> _legacy_seeding -> mt19937_seed (Knuth's init_genrand)
+    uint32_t prev = seed;
+    key[0] = prev;
+    for (int i = 1; i < kMtN; ++i) {
+        prev = 1812433253u * (prev ^ (prev >> 30)) + static_cast<uint32_t>(i);
+        key[i] = prev;
+    }
+    *pos = kMtN;
+}
+
+MZ_HD inline uint32_t mt_mix(uint32_t hi, uint32_t lo, uint32_t far) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+MZ_HD inline void mt_regenerate(uint32_t* key) {
+    int k = 0;
+    for (; k < kMtN - kMtM; ++k) key[k] = mt_mix(key[k], key[k + 1], key[k + kMtM]);
+    for (; k < kMtN - 1; ++k) key[k] = mt_mix(key[k], key[k + 1], key[k + kMtM - kMtN]);
+    key[kMtN - 1] = mt_mix(key[kMtN - 1], key[0], key[kMtM - 1]);
+}
+
+MZ_HD inline uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+MZ_HD inline uint32_t mt_next(uint32_t* key, int32_t* pos) {
+    int32_t p = *pos;
+    if (p >= kMtN) {
+        mt_regenerate(key);
+        p = 0;
+    }
+    const uint32_t y = key[p];
+    *pos = p + 1;
+    return mt_temper(y);
+}
+
+// smallest 2^m - 1 >= v
+MZ_HD inline uint32_t mask_for(uint32_t v) {
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    return v;
+}
+
+// RandomState.randint(0, n) as reached from choice(list-of-n): masked rejection on 32-bit words;
+// n == 1 consumes nothing.  `words` counts the draws.
+MZ_HD inline uint32_t mt_below(uint32_t* key, int32_t* pos, uint32_t n, uint32_t* words) {
+    const uint32_t top = n - 1u;
+    if (top == 0u) return 0u;
+    const uint32_t mask = mask_for(top);
+    uint32_t v;
+    do {
+        v = mt_next(key, pos) & mask;
+        ++*words;
+    } while (v > top);
+    return v;
+}
+
+// ---- host stream: the full legacy distribution set the path needs -----------------------------
+struct HostStream {
+    uint32_t key[kMtN];
+    int32_t pos = kMtN;
+    int32_t has_gauss = 0;
+    double gauss = 0.0;
+    uint64_t words = 0;  // 32-bit words drawn since construction / seeding
+
+    void seed(uint32_t s) {
+        mt_seed(key, &pos, s);
+        has_gauss = 0;
+        gauss = 0.0;
+        words = 0;
+    }
+    uint32_t u32() {
+        ++words;
+        return mt_next(key, &pos);
+    }
+    void skip(uint64_t n) {
+        for (uint64_t i = 0; i < n; ++i) u32();
+    }
+    // legacy_double: 53 random bits from two words
+    double uniform() {
+        const int32_t a = static_cast<int32_t>(u32() >> 5);
+        const int32_t b = static_cast<int32_t>(u32() >> 6);
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    uint32_t below(uint32_t n) {
+        uint32_t w = 0;
+        const uint32_t v = mt_below(key, &pos, n, &w);
+        words += w;
+        return v;
+    }
+    double exponential() { return -std::log(1.0 - uniform()); }
+    double normal() {  // legacy_gauss: polar Box-Muller with a one-value cache
+        if (has_gauss) {
+            const double t = gauss;
+            has_gauss = 0;
+            gauss = 0.0;
+            return t;
+        }
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * uniform() - 1.0;
+            x2 = 2.0 * uniform() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+        gauss = f * x1;
+        has_gauss = 1;
+        return f * x2;
+    }
+    double gamma(double shape) {  // legacy_standard_gamma
+        if (shape == 1.0) return exponential();
+        if (shape == 0.0) return 0.0;
+        if (shape < 1.0) {
+            for (;;) {
+                const double u = uniform();
+                const double v = exponential();
+                if (u <= 1.0 - shape) {
+                    const double x = std::pow(u, 1. / shape);
+                    if (x <= v) return x;
+                } else {
+                    const double y = -std::log((1 - u) / shape);
+                    const double x = std::pow(1.0 - shape + shape * y, 1. / shape);
+                    if (x <= (v + y)) return x;
+                }
+            }
+        }
+        const double b = shape - 1. / 3.;
+        const double c = 1. / std::sqrt(9 * b);
+        for (;;) {
+            double x, v;
+            do {
+                x = normal();
+                v = 1.0 + c * x;
+            } while (v <= 0.0);
+            v = v * v * v;
+            const double u = uniform();
+            if (u < 1.0 - 0.0331 * (x * x) * (x * x)) return b * v;
+            if (std::log(u) < 0.5 * x * x + b * (1. - v + std::log(v))) return b * v;
+        }
+    }
+    // RandomState.dirichlet([alpha] * k)
+    void dirichlet(double alpha, int k, double* out) {
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) {
+            out[j] = gamma(alpha);
+            acc = acc + out[j];
+        }
+        const double inv = 1 / acc;
+        for (int j = 0; j < k; ++j) out[j] = out[j] * inv;
+    }
+    // RandomState.choice(n, p=p): normalised cumulative sum, one uniform, right-bisect
+    int choice_p(const double* p, int n) {
+        double total = 0.0;
+        for (int i = 0; i < n; ++i) total += p[i];
+        const double u = uniform();
+        double run = 0.0;
+        int idx = 0;
+        for (; idx < n; ++idx) {
+            run += p[idx];
+            if (!(run / total <= u)) break;
+        }
+        return idx;
+    }
+    // SelfPlay.select_action (self_play.py:223-246) -> chosen slot
+    int select_action(const int32_t* visits, int n, double temperature) {
+        if (temperature == 0) {
+            int best = 0;
+            for (int i = 1; i < n; ++i)
+                if (visits[i] > visits[best]) best = i;
+            return best;
+        }
+        if (std::isinf(temperature)) return static_cast<int>(below(static_cast<uint32_t>(n)));
+        double stack_buf[64];
+        double* w = n <= 64 ? stack_buf : new double[n];
+        double total = 0;
+        for (int i = 0; i < n; ++i) {
+            w[i] = std::pow(static_cast<double>(visits[i]), 1 / temperature);
+            total = total + w[i];
+        }
+        for (int i = 0; i < n; ++i) w[i] = w[i] / total;
+        const int pick = choice_p(w, n);
+        if (w != stack_buf) delete[] w;
+        return pick;
+    }
+};
+}  // namespace mz

@@ -1,0 +1,76 @@
+// tree_layout.h -- device data layout of the batched search trees (gfx950 / MI355X).
+//
+// E independent trees are searched in lock step.  Simulation s expands exactly one node per tree,
+// so "expanded node k" (k = 0 for the root, k = s+1 for the node expanded by simulation s) is a
+// dense index shared by all trees, and every pool is laid out [k][e][...]:
+//
+//   child blocks   [(S+1)][E] blocks of `block_stride` bytes.  Block (k,e) holds the A children of
+//                  expanded node k of tree e as two 16-byte-wide member arrays (struct-of-arrays
+//                  inside the block, so one lane per child reads two fully coalesced dwordx4):
+//                      ChildStats stats[A]   { f64 value_sum; f64 prior }
+//                      ChildLinks links[A]   { f32 reward; i32 visits; i32 child_node; i32 pad }
+//                  32*A bytes, padded to a multiple of 64 B (CartPole A=2: exactly one 64-B line per
+//                  descent step).  Writes of a whole slab k by expand are contiguous over (e, child).
+//   hidden pool    f32 [(S+1)][E][H]: the state of expanded node k.  The network writes slab s+1
+//                  as one contiguous [E,H] matrix; select gathers rows (k_e, e) into a batch.
+//   path           i32 [S][E]: level d of the current descent, packed (parent k << 16 | slot).
+//   per-tree [E]   min-max stats, root value sum / reward, counters, RNG position.
+//   RNG            u32 [E][624] MT19937 keys (numpy legacy clone), see np_legacy_rng.h.
+//
+// to_play is not stored: with players == range(P) the reference's virtual_to_play rotation
+// (self_play.py:332-335) makes it (root_to_play + tree_depth) mod P.
+#pragma once
+#include <cstdint>
+
+namespace mz {
+
+struct alignas(16) ChildStats {
+    double value_sum;  // Node.value_sum (self_play.py:439)
+    double prior;      // Node.prior
+};
+
+struct alignas(16) ChildLinks {
+    float reward;        // Node.reward: always an fp32 value (.item() of an fp32 tensor, self_play.py:345)
+    int32_t visits;      // Node.visit_count
+    int32_t child_node;  // expanded-node index of this child, -1 while it is a leaf (not expanded)
+    int32_t pad;
+};
+
+struct alignas(16) MinMax {
+    double minimum, maximum;  // MinMaxStats (self_play.py:551-568)
+};
+
+struct TreeParams {
+    int32_t E, A, S, P, F, support, H;
+    int32_t chunks;          // ceil(A / 64) when A > 64, else 1
+    uint32_t block_stride;   // bytes per child block
+    uint32_t links_offset;   // 16 * A
+    double discount;
+    double noise_frac;
+    // pools
+    uint8_t* blocks;
+    float* hidden;
+    int32_t* path;
+    int32_t* path_ties;      // optional [S][E] tie-list sizes (debug / parity tests), may be null
+    int32_t* path_len;       // [E] depth of the current descent
+    int32_t* leaf_parent;    // [E] expanded-node index of the leaf's parent (hidden-state slab)
+    MinMax* min_max;         // [E]
+    double* root_value_sum;  // [E]
+    double* root_reward;     // [E]
+    float* root_predicted;   // [E]
+    int32_t* root_children;  // [E] number of root children; 0 = tree inactive this search
+    int32_t* root_to_play;   // [E]
+    int32_t* root_action;    // [E][A] slot -> action at the root
+    int32_t* max_depth;      // [E]
+    int64_t* depth_sum;      // [E]
+    uint32_t* tie_words;     // [E]
+    uint32_t* mt_key;        // [E][624]
+    int32_t* mt_pos;         // [E]
+    const double* pbc_log;   // [S+1] log((N + base + 1)/base) + init   (host libm, self_play.py:385-390)
+    const double* pbc_sqrt;  // [S+1] sqrt(N)
+    int32_t* error_flag;     // sticky device-side error word
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace mz

@@ -1,0 +1,318 @@
+"""BatchedMCTS: the Python host that drives libmzmcts.so for E trees in lock step.
+
+One search (= the reference's `MCTS.run`, self_play.py:261-362, for every env at once):
+
+    roots      initial_inference on the [E,...] observation batch (PyTorch-ROCm)
+               begin_search  (host: contract checks, Dirichlet noise on the per-env RNG mirrors)
+               expand_roots  (HIP: decode, masked fp32 softmax, noise mix, per-search reset)
+    S times    select        (HIP: UCB descent for all trees + hidden-state gather)
+               recurrent_inference on the gathered [E,H] batch (PyTorch-ROCm, MFMA GEMMs/convs),
+                             next state written straight into the pool slab
+               expand_backup (HIP: decode, expand, LDS-staged backup, min-max)
+    readout    root statistics to the host, action sampling on the RNG mirrors
+
+After the first (eager, warm-up) search the S-simulation loop can be captured once into a hipGraph
+(`torch.cuda.CUDAGraph`; the C-ABI launch functions neither allocate nor synchronise) and replayed
+per move, which removes the per-launch host cost of ~30 small kernels per simulation.
+
+PyTorch is plumbing here (device memory, streams, the network modules); the tree work is in the
+HIP library and there is no fallback if it is missing.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import MzConfig, MzProfile, MzRootStats, c_f64_p, c_i32_p, c_i64_p, c_u32_p, ptr
+
+
+def hidden_state_shape(config):
+    """Shape of one hidden state (without batch) for a MuZeroConfig (models.py:80-127, 432-516)."""
+    if config.network == "fullyconnected":
+        return (config.encoding_size,)
+    _, h, w = config.observation_shape
+    if config.downsample:
+        h, w = math.ceil(h / 16), math.ceil(w / 16)
+    return (config.channels, h, w)
+
+
+class BatchedMCTS:
+    def __init__(self, config, num_envs, device=None, seeds=None, use_graph=False):
+        if len(config.players) > 2:
+            raise NotImplementedError("More than two player mode not implemented.")
+        if list(config.players) != list(range(len(config.players))):
+            raise NotImplementedError("players must be list(range(n)) (the reference's only supported form)")
+        if list(config.action_space) != list(range(len(config.action_space))):
+            raise NotImplementedError("action_space must be list(range(n)) (the reference's only supported form)")
+        self._lib = _native.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedMCTS needs a HIP device (MI355X); there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.E = int(num_envs)
+        self.A = len(config.action_space)
+        self.S = int(config.num_simulations)
+        self.F = 2 * config.support_size + 1
+        self.state_shape = hidden_state_shape(config)
+        self.H = int(np.prod(self.state_shape))
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._eager_searches = 0
+        self._graph_model = None
+        self._profiling = False
+
+        with torch.cuda.device(self.device):
+            self.pool = torch.empty((self.S + 1, self.E, self.H), dtype=torch.float32, device=self.device)
+            self.batch_hidden = torch.zeros((self.E, self.H), dtype=torch.float32, device=self.device)
+            self.batch_action = torch.zeros((self.E, 1), dtype=torch.int64, device=self.device)
+        cfg = MzConfig(num_envs=self.E, num_actions=self.A, num_simulations=self.S,
+                       num_players=len(config.players), support_size=int(config.support_size),
+                       hidden_floats=self.H, device=self.device.index, reserved=0,
+                       discount=float(config.discount), pb_c_base=float(config.pb_c_base),
+                       pb_c_init=float(config.pb_c_init),
+                       root_dirichlet_alpha=float(config.root_dirichlet_alpha),
+                       root_exploration_fraction=float(config.root_exploration_fraction),
+                       hidden_pool=self.pool.data_ptr())
+        handle = ctypes.c_void_p()
+        rc = self._lib.mzmcts_create(ctypes.byref(cfg), ctypes.byref(handle))
+        _native.check(self._lib, None, rc)
+        self._h = handle
+        if seeds is None:
+            seeds = [int(config.seed) + e for e in range(self.E)]  # worker e: config.seed + e (muzero.py:175)
+        self.seed(seeds)
+
+        # host result buffers
+        E, A = self.E, self.A
+        self._legal = np.zeros((E, A), dtype=np.int32)
+        self._nlegal = np.zeros(E, dtype=np.int32)
+        self._to_play = np.zeros(E, dtype=np.int32)
+        self.noise = np.zeros((E, A), dtype=np.float64)
+        self.stats = dict(
+            visits=np.zeros((E, A), np.int32), child_value_sum=np.zeros((E, A)),
+            child_prior=np.zeros((E, A)), child_reward=np.zeros((E, A)),
+            child_expanded=np.zeros((E, A), np.int32), root_value_sum=np.zeros(E),
+            root_visits=np.zeros(E, np.int32), max_tree_depth=np.zeros(E, np.int32),
+            root_predicted_value=np.zeros(E), min_max=np.zeros((E, 2)),
+            depth_sum=np.zeros(E, np.int64), tie_break_words=np.zeros(E, np.uint32))
+        s = self.stats
+        self._stats_struct = MzRootStats(
+            ptr(s["visits"], c_i32_p), ptr(s["child_value_sum"], c_f64_p), ptr(s["child_prior"], c_f64_p),
+            ptr(s["child_reward"], c_f64_p), ptr(s["child_expanded"], c_i32_p),
+            ptr(s["root_value_sum"], c_f64_p), ptr(s["root_visits"], c_i32_p),
+            ptr(s["max_tree_depth"], c_i32_p), ptr(s["root_predicted_value"], c_f64_p),
+            ptr(s["min_max"], c_f64_p), ptr(s["depth_sum"], c_i64_p), ptr(s["tie_break_words"], c_u32_p))
+
+    # ------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._graph = None
+            self._lib.mzmcts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        _native.check(self._lib, self._h, rc)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- RNG ------------------------------------------------------------------------------------
+    def seed(self, seeds):
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+        assert seeds.shape == (self.E,)
+        self._check(self._lib.mzmcts_seed(self._h, ptr(seeds, c_u32_p), self._stream()))
+
+    def set_rng_state(self, env, state):
+        """state: the tuple numpy.random.get_state() returns."""
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        self._check(self._lib.mzmcts_rng_set_state(self._h, env, ptr(key, c_u32_p), int(state[2]),
+                                                   int(state[3]), float(state[4]), self._stream()))
+
+    def get_rng_state(self, env):
+        key = np.zeros(624, dtype=np.uint32)
+        pos, hg, g = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        self._check(self._lib.mzmcts_rng_get_state(self._h, env, ptr(key, c_u32_p), ctypes.byref(pos),
+                                                   ctypes.byref(hg), ctypes.byref(g), self._stream()))
+        return ("MT19937", key, pos.value, hg.value, g.value)
+
+    # ---- low-level steps (also what the parity tests drive) -------------------------------------
+    def begin_search(self, legal_actions, to_play, add_exploration_noise=True):
+        """legal_actions: per env a sequence of actions (empty / None = env inactive this search)."""
+        self._legal[:] = 0
+        for e, legal in enumerate(legal_actions):
+            n = 0 if legal is None else len(legal)
+            if n > self.A:
+                raise AssertionError("Legal actions should be a subset of the action space.")
+            self._nlegal[e] = n
+            if n:
+                self._legal[e, :n] = legal
+        self._to_play[:] = np.asarray(to_play, dtype=np.int32)
+        self._check(self._lib.mzmcts_begin_search(
+            self._h, ptr(self._legal, c_i32_p), ptr(self._nlegal, c_i32_p), ptr(self._to_play, c_i32_p),
+            1 if add_exploration_noise else 0, ptr(self.noise, c_f64_p), self._stream()))
+
+    def expand_roots(self, value_logits, reward_logits, policy_logits, root_hidden=None):
+        v, p = self._f32(value_logits, self.F), self._f32(policy_logits, self.A)
+        r = None if reward_logits is None else self._f32(reward_logits, self.F)
+        h = None if root_hidden is None else self._f32(root_hidden.reshape(self.E, -1), self.H)
+        self._keep = (v, r, p, h)
+        self._check(self._lib.mzmcts_expand_roots(
+            self._h, v.data_ptr(), None if r is None else r.data_ptr(), p.data_ptr(),
+            None if h is None else h.data_ptr(), self._stream()))
+
+    def expand_roots_injected(self, root_reward, root_priors):
+        r = torch.as_tensor(np.asarray(root_reward, dtype=np.float64), device=self.device).contiguous()
+        p = torch.as_tensor(np.asarray(root_priors, dtype=np.float64), device=self.device).contiguous()
+        assert r.shape == (self.E,) and p.shape == (self.E, self.A)
+        self._keep = (r, p)
+        self._check(self._lib.mzmcts_expand_roots_injected(self._h, r.data_ptr(), p.data_ptr(), self._stream()))
+
+    def select(self, gather=True):
+        self._check(self._lib.mzmcts_select(
+            self._h, self.batch_hidden.data_ptr() if gather and self.H else None,
+            self.batch_action.data_ptr(), self._stream()))
+
+    def expand_backup(self, value_logits, reward_logits, policy_logits, next_hidden=None):
+        v, r, p = self._f32(value_logits, self.F), self._f32(reward_logits, self.F), self._f32(policy_logits, self.A)
+        h = None if next_hidden is None else self._f32(next_hidden.reshape(self.E, -1), self.H)
+        self._keep = (v, r, p, h)
+        self._check(self._lib.mzmcts_expand_backup(
+            self._h, v.data_ptr(), r.data_ptr(), p.data_ptr(), None if h is None else h.data_ptr(),
+            self._stream()))
+
+    def expand_backup_injected(self, value, reward, priors):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float64), device=self.device).contiguous()
+        r = torch.as_tensor(np.asarray(reward, dtype=np.float64), device=self.device).contiguous()
+        p = torch.as_tensor(np.asarray(priors, dtype=np.float64), device=self.device).contiguous()
+        assert v.shape == (self.E,) and r.shape == (self.E,) and p.shape == (self.E, self.A)
+        self._keep = (v, r, p)
+        self._check(self._lib.mzmcts_expand_backup_injected(self._h, v.data_ptr(), r.data_ptr(),
+                                                            p.data_ptr(), self._stream()))
+
+    def _f32(self, t, width):
+        assert t.is_cuda and t.dtype == torch.float32, "network outputs must be fp32 device tensors"
+        t = t.contiguous()
+        assert t.shape == (self.E, width), f"expected shape {(self.E, width)}, got {tuple(t.shape)}"
+        return t
+
+    def next_slab(self):
+        """Pool slab (as an [E, *state_shape] view) the coming expand_backup will own."""
+        k = self._lib.mzmcts_next_slab(self._h)
+        return self.pool[k].view(self.E, *self.state_shape)
+
+    def simulations_done(self):
+        return self._lib.mzmcts_simulations_done(self._h)
+
+    def last_paths(self, with_ties=False):
+        depth = np.zeros(self.E, np.int32)
+        actions = np.zeros((self.E, self.S), np.int32)
+        ties = np.zeros((self.E, self.S), np.int32) if with_ties else None
+        self._check(self._lib.mzmcts_last_paths(self._h, ptr(depth, c_i32_p), ptr(actions, c_i32_p),
+                                                ptr(ties, c_i32_p), self._stream()))
+        return depth, actions, ties
+
+    def set_debug_ties(self, enabled=True):
+        self._check(self._lib.mzmcts_set_debug_ties(self._h, 1 if enabled else 0))
+
+    def export_tree(self, env):
+        n = (self.S + 1) * self.A
+        out = dict(visits=np.zeros(n, np.int32), value_sum=np.zeros(n), prior=np.zeros(n),
+                   reward=np.zeros(n), child_node=np.zeros(n, np.int32))
+        self._check(self._lib.mzmcts_export_tree(
+            self._h, env, ptr(out["visits"], c_i32_p), ptr(out["value_sum"], c_f64_p),
+            ptr(out["prior"], c_f64_p), ptr(out["reward"], c_f64_p), ptr(out["child_node"], c_i32_p),
+            self._stream()))
+        return {k: v.reshape(self.S + 1, self.A) for k, v in out.items()}
+
+    # ---- the simulation loop ---------------------------------------------------------------------
+    def _simulate_once(self, model):
+        self.select()
+        slab = self.next_slab()
+        value, reward, policy, _ = model.recurrent_inference(
+            self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)
+        self.expand_backup(value, reward, policy, None)
+
+    def _run_simulations(self, model):
+        graph_ok = self.use_graph and not self._profiling
+        if graph_ok and self._graph is not None and self._graph_model is model:
+            self._check(self._lib.mzmcts_set_simulations_done(self._h, 0))
+            self._graph.replay()
+            self._check(self._lib.mzmcts_set_simulations_done(self._h, self.S))
+            return
+        if graph_ok and self._eager_searches >= 1:
+            # capture the S-simulation loop once; capture records, the replay below executes
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.graph(graph):
+                for _ in range(self.S):
+                    self._simulate_once(model)
+            self._graph, self._graph_model = graph, model
+            self._check(self._lib.mzmcts_set_simulations_done(self._h, 0))
+            graph.replay()
+            self._check(self._lib.mzmcts_set_simulations_done(self._h, self.S))
+            return
+        for _ in range(self.S):
+            self._simulate_once(model)
+        self._eager_searches += 1
+
+    @torch.no_grad()
+    def search(self, model, observations, legal_actions, to_play, add_exploration_noise=True):
+        """MCTS.run for all envs.  observations: [E, C, H, W] (numpy or tensor)."""
+        obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
+        obs = obs.to(self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            value, reward, policy, hidden = model.initial_inference(obs)
+            self.begin_search(legal_actions, to_play, add_exploration_noise)
+            self.expand_roots(value, reward.contiguous(), policy, hidden)
+            self._run_simulations(model)
+            return self.readout()
+
+    def readout(self):
+        self._check(self._lib.mzmcts_readout(self._h, ctypes.byref(self._stats_struct), self._stream()))
+        return self.stats
+
+    def sample_actions(self, temperature):
+        """SelfPlay.select_action per env on its own RNG stream; returns (actions, slots)."""
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+        actions = np.zeros(self.E, np.int32)
+        slots = np.zeros(self.E, np.int32)
+        self._check(self._lib.mzmcts_sample_actions(self._h, ptr(t, c_f64_p), ptr(actions, c_i32_p),
+                                                    ptr(slots, c_i32_p)))
+        return actions, slots
+
+    def search_statistics(self):
+        """GameHistory.store_search_statistics targets: (child_visits [E,A], root_values [E])."""
+        cv = np.zeros((self.E, self.A))
+        rv = np.zeros(self.E)
+        self._check(self._lib.mzmcts_search_statistics(self._h, ptr(cv, c_f64_p), ptr(rv, c_f64_p)))
+        return cv, rv
+
+    # ---- measurement -------------------------------------------------------------------------------
+    def set_profiling(self, enabled):
+        self._profiling = bool(enabled)
+        self._check(self._lib.mzmcts_set_profiling(self._h, 1 if enabled else 0))
+
+    def get_profile(self, reset=True):
+        prof = MzProfile()
+        self._check(self._lib.mzmcts_get_profile(self._h, ctypes.byref(prof), 1 if reset else 0))
+        return {name: getattr(prof, name) for name, _ in MzProfile._fields_}
+
+    def device_bytes(self):
+        return int(self._lib.mzmcts_device_bytes(self._h)) + self.pool.numel() * 4
+
+    def algorithmic_bytes_per_simulation(self, mean_depth):
+        """SURVEY.md section 8(d) formula: bytes one simulation of one tree must move, split by kernel."""
+        A, H, F = self.A, self.H, self.F
+        two = 1 if len(self.config.players) == 2 else 0
+        select = mean_depth * (8 + 24 * A) + 2 * 4 * H
+        backup = (mean_depth + 1) * (28 + two) + 32 + 24 * A + 13 + 4 * (A + 2 * F)
+        return dict(select=select, expand_backup=backup, total=select + backup)

@@ -1,0 +1,383 @@
+"""Inference half of the reference's networks (reference models.py), run through PyTorch-ROCm.
+
+Same factory (`MuZeroNetwork(config)`), same method names (`initial_inference`,
+`recurrent_inference`, `get_weights`, `set_weights`) and -- so that reference checkpoints and
+trainer weights load unchanged -- the same state-dict keys, including the `.module.` level the
+reference gets from wrapping every sub-network in `torch.nn.DataParallel` (models.py:98-126,
+482-516).  Here `.module.` comes from a transparent holder instead: one process drives one GPU, so
+there is nothing to scatter.
+
+Differences that matter on the GPU hot path (values are unchanged):
+  * no host synchronisation: the `scale[scale < 1e-5] += 1e-5` mask-assignment (a device->host sync
+    via nonzero) is a `torch.where`, so a whole simulation can be captured into a hipGraph;
+  * `recurrent_inference(..., out_state=...)` writes the normalised next state straight into the
+    engine's hidden-state pool slab, saving a copy per simulation;
+  * `support_to_scalar` keeps its support vector resident instead of rebuilding it per call.
+"""
+import math
+
+import torch
+
+
+class MuZeroNetwork:
+    """Factory, reference models.py:7-41."""
+
+    def __new__(cls, config):
+        if config.network == "fullyconnected":
+            return MuZeroFullyConnectedNetwork(
+                config.observation_shape, config.stacked_observations, len(config.action_space),
+                config.encoding_size, config.fc_reward_layers, config.fc_value_layers,
+                config.fc_policy_layers, config.fc_representation_layers, config.fc_dynamics_layers,
+                config.support_size)
+        if config.network == "resnet":
+            return MuZeroResidualNetwork(
+                config.observation_shape, config.stacked_observations, len(config.action_space),
+                config.blocks, config.channels, config.reduced_channels_reward,
+                config.reduced_channels_value, config.reduced_channels_policy,
+                config.resnet_fc_reward_layers, config.resnet_fc_value_layers,
+                config.resnet_fc_policy_layers, config.support_size, config.downsample)
+        raise NotImplementedError('The network parameter should be "fullyconnected" or "resnet".')
+
+
+def dict_to_cpu(dictionary):
+    """reference models.py:44-53"""
+    out = {}
+    for key, value in dictionary.items():
+        if isinstance(value, torch.Tensor):
+            out[key] = value.cpu()
+        elif isinstance(value, dict):
+            out[key] = dict_to_cpu(value)
+        else:
+            out[key] = value
+    return out
+
+
+class _Replica(torch.nn.Module):
+    """Holds a sub-network under the attribute name `module`, which is all DataParallel contributes
+    to the reference's state-dict keys."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args):
+        return self.module(*args)
+
+
+def mlp(input_size, layer_sizes, output_size, output_activation=torch.nn.Identity,
+        activation=torch.nn.ELU):
+    """Linear/ELU stack with an identity head; Sequential indices 0,2,4.. are the Linear layers
+    (reference models.py:626-638)."""
+    widths = [input_size, *layer_sizes, output_size]
+    stack = []
+    last = len(widths) - 2
+    for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+        stack.append(torch.nn.Linear(fan_in, fan_out))
+        stack.append(activation() if i < last else output_activation())
+    return torch.nn.Sequential(*stack)
+
+
+def _unit_rescale(x, dims):
+    """Min-max rescale to [0,1] over `dims` (reference models.py:137-145, 525-549)."""
+    low = x.amin(dim=dims, keepdim=True)
+    high = x.amax(dim=dims, keepdim=True)
+    span = high - low
+    span = torch.where(span < 1e-5, span + 1e-5, span)
+    return x - low, span
+
+
+class AbstractNetwork(torch.nn.Module):
+    """reference models.py:56-73"""
+
+    def initial_inference(self, observation):
+        raise NotImplementedError
+
+    def recurrent_inference(self, encoded_state, action, out_state=None):
+        raise NotImplementedError
+
+    def get_weights(self):
+        return dict_to_cpu(self.state_dict())
+
+    def set_weights(self, weights):
+        self.load_state_dict(weights)
+
+    def _zero_reward_logits(self, batch, device):
+        # log(one_hot(centre)): -inf everywhere, 0 at the centre (reference models.py:176-183)
+        cached = getattr(self, "_zero_reward_cache", None)
+        if cached is None or cached.device != device:
+            row = torch.full((1, self.full_support_size), float("-inf"), device=device)
+            row[0, self.full_support_size // 2] = 0.0
+            self._zero_reward_cache = cached = row
+        return cached.expand(batch, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fully connected (reference models.py:80-195)
+# ------------------------------------------------------------------------------------------------
+class MuZeroFullyConnectedNetwork(AbstractNetwork):
+    def __init__(self, observation_shape, stacked_observations, action_space_size, encoding_size,
+                 fc_reward_layers, fc_value_layers, fc_policy_layers, fc_representation_layers,
+                 fc_dynamics_layers, support_size):
+        super().__init__()
+        self.action_space_size = action_space_size
+        self.full_support_size = 2 * support_size + 1
+        c, h, w = observation_shape
+        flat_obs = c * h * w * (stacked_observations + 1) + stacked_observations * h * w
+        self.representation_network = _Replica(mlp(flat_obs, fc_representation_layers, encoding_size))
+        self.dynamics_encoded_state_network = _Replica(
+            mlp(encoding_size + action_space_size, fc_dynamics_layers, encoding_size))
+        self.dynamics_reward_network = _Replica(
+            mlp(encoding_size, fc_reward_layers, self.full_support_size))
+        self.prediction_policy_network = _Replica(
+            mlp(encoding_size, fc_policy_layers, action_space_size))
+        self.prediction_value_network = _Replica(
+            mlp(encoding_size, fc_value_layers, self.full_support_size))
+
+    def prediction(self, encoded_state):
+        return (self.prediction_policy_network(encoded_state),
+                self.prediction_value_network(encoded_state))
+
+    def representation(self, observation):
+        raw = self.representation_network(observation.reshape(observation.shape[0], -1))
+        shifted, span = _unit_rescale(raw, 1)
+        return shifted / span
+
+    def dynamics(self, encoded_state, action, out_state=None):
+        one_hot = (action.long() == torch.arange(self.action_space_size, device=action.device)
+                   ).to(encoded_state.dtype)
+        raw = self.dynamics_encoded_state_network(torch.cat((encoded_state, one_hot), dim=1))
+        reward = self.dynamics_reward_network(raw)  # on the un-normalised state (models.py:157-159)
+        shifted, span = _unit_rescale(raw, 1)
+        return torch.div(shifted, span, out=out_state), reward
+
+    def initial_inference(self, observation):
+        encoded_state = self.representation(observation)
+        policy_logits, value = self.prediction(encoded_state)
+        reward = self._zero_reward_logits(observation.shape[0], observation.device)
+        return value, reward, policy_logits, encoded_state
+
+    def recurrent_inference(self, encoded_state, action, out_state=None):
+        next_state, reward = self.dynamics(encoded_state, action, out_state)
+        policy_logits, value = self.prediction(next_state)
+        return value, reward, policy_logits, next_state
+
+
+# ------------------------------------------------------------------------------------------------
+# Residual (reference models.py:206-619)
+# ------------------------------------------------------------------------------------------------
+def conv3x3(in_channels, out_channels, stride=1):
+    return torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1,
+                           bias=False)
+
+
+class ResidualBlock(torch.nn.Module):
+    def __init__(self, num_channels, stride=1):
+        super().__init__()
+        self.conv1 = conv3x3(num_channels, num_channels, stride)
+        self.bn1 = torch.nn.BatchNorm2d(num_channels)
+        self.conv2 = conv3x3(num_channels, num_channels)
+        self.bn2 = torch.nn.BatchNorm2d(num_channels)
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y += x
+        return torch.relu(y)
+
+
+def _tower(channels, count):
+    return torch.nn.ModuleList([ResidualBlock(channels) for _ in range(count)])
+
+
+class DownSample(torch.nn.Module):
+    """Strided residual down-sampler (reference models.py:233-275)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        half = out_channels // 2
+        self.conv1 = torch.nn.Conv2d(in_channels, half, kernel_size=3, stride=2, padding=1, bias=False)
+        self.resblocks1 = _tower(half, 2)
+        self.conv2 = torch.nn.Conv2d(half, out_channels, kernel_size=3, stride=2, padding=1, bias=False)
+        self.resblocks2 = _tower(out_channels, 3)
+        self.pooling1 = torch.nn.AvgPool2d(kernel_size=3, stride=2, padding=1)
+        self.resblocks3 = _tower(out_channels, 3)
+        self.pooling2 = torch.nn.AvgPool2d(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        stages = ((self.conv1, self.resblocks1), (self.conv2, self.resblocks2),
+                  (self.pooling1, self.resblocks3))
+        for head, tower in stages:
+            x = head(x)
+            for block in tower:
+                x = block(x)
+        return self.pooling2(x)
+
+
+class DownsampleCNN(torch.nn.Module):
+    """Light convolutional down-sampler (reference models.py:278-297)."""
+
+    def __init__(self, in_channels, out_channels, h_w):
+        super().__init__()
+        mid = (in_channels + out_channels) // 2
+        self.features = torch.nn.Sequential(
+            torch.nn.Conv2d(in_channels, mid, kernel_size=h_w[0] * 2, stride=4, padding=2),
+            torch.nn.ReLU(inplace=True),
+            torch.nn.MaxPool2d(kernel_size=3, stride=2),
+            torch.nn.Conv2d(mid, out_channels, kernel_size=5, padding=2),
+            torch.nn.ReLU(inplace=True),
+            torch.nn.MaxPool2d(kernel_size=3, stride=2),
+        )
+        self.avgpool = torch.nn.AdaptiveAvgPool2d(h_w)
+
+    def forward(self, x):
+        return self.avgpool(self.features(x))
+
+
+class RepresentationNetwork(torch.nn.Module):
+    def __init__(self, observation_shape, stacked_observations, num_blocks, num_channels, downsample):
+        super().__init__()
+        in_planes = observation_shape[0] * (stacked_observations + 1) + stacked_observations
+        self.downsample = downsample
+        if downsample:
+            if downsample == "resnet":
+                self.downsample_net = DownSample(in_planes, num_channels)
+            elif downsample == "CNN":
+                self.downsample_net = DownsampleCNN(
+                    in_planes, num_channels,
+                    (math.ceil(observation_shape[1] / 16), math.ceil(observation_shape[2] / 16)))
+            else:
+                raise NotImplementedError('downsample should be "resnet" or "CNN".')
+        # built even when a down-sampler replaces it: it is part of the reference's state dict
+        self.conv = conv3x3(in_planes, num_channels)
+        self.bn = torch.nn.BatchNorm2d(num_channels)
+        self.resblocks = _tower(num_channels, num_blocks)
+
+    def forward(self, x):
+        x = self.downsample_net(x) if self.downsample else torch.relu(self.bn(self.conv(x)))
+        for block in self.resblocks:
+            x = block(x)
+        return x
+
+
+class DynamicsNetwork(torch.nn.Module):
+    def __init__(self, num_blocks, num_channels, reduced_channels_reward, fc_reward_layers,
+                 full_support_size, block_output_size_reward):
+        super().__init__()
+        self.conv = conv3x3(num_channels, num_channels - 1)
+        self.bn = torch.nn.BatchNorm2d(num_channels - 1)
+        self.resblocks = _tower(num_channels - 1, num_blocks)
+        self.conv1x1_reward = torch.nn.Conv2d(num_channels - 1, reduced_channels_reward, 1)
+        self.block_output_size_reward = block_output_size_reward
+        self.fc = mlp(block_output_size_reward, fc_reward_layers, full_support_size)
+
+    def forward(self, x):
+        x = torch.relu(self.bn(self.conv(x)))
+        for block in self.resblocks:
+            x = block(x)
+        reward = self.fc(self.conv1x1_reward(x).reshape(-1, self.block_output_size_reward))
+        return x, reward
+
+
+class PredictionNetwork(torch.nn.Module):
+    def __init__(self, action_space_size, num_blocks, num_channels, reduced_channels_value,
+                 reduced_channels_policy, fc_value_layers, fc_policy_layers, full_support_size,
+                 block_output_size_value, block_output_size_policy):
+        super().__init__()
+        self.resblocks = _tower(num_channels, num_blocks)
+        self.conv1x1_value = torch.nn.Conv2d(num_channels, reduced_channels_value, 1)
+        self.conv1x1_policy = torch.nn.Conv2d(num_channels, reduced_channels_policy, 1)
+        self.block_output_size_value = block_output_size_value
+        self.block_output_size_policy = block_output_size_policy
+        self.fc_value = mlp(block_output_size_value, fc_value_layers, full_support_size)
+        self.fc_policy = mlp(block_output_size_policy, fc_policy_layers, action_space_size)
+
+    def forward(self, x):
+        for block in self.resblocks:
+            x = block(x)
+        value = self.fc_value(self.conv1x1_value(x).reshape(-1, self.block_output_size_value))
+        policy = self.fc_policy(self.conv1x1_policy(x).reshape(-1, self.block_output_size_policy))
+        return policy, value
+
+
+class MuZeroResidualNetwork(AbstractNetwork):
+    def __init__(self, observation_shape, stacked_observations, action_space_size, num_blocks,
+                 num_channels, reduced_channels_reward, reduced_channels_value,
+                 reduced_channels_policy, fc_reward_layers, fc_value_layers, fc_policy_layers,
+                 support_size, downsample):
+        super().__init__()
+        self.action_space_size = action_space_size
+        self.full_support_size = 2 * support_size + 1
+        if downsample:
+            plane = math.ceil(observation_shape[1] / 16) * math.ceil(observation_shape[2] / 16)
+        else:
+            plane = observation_shape[1] * observation_shape[2]
+        self.representation_network = _Replica(RepresentationNetwork(
+            observation_shape, stacked_observations, num_blocks, num_channels, downsample))
+        self.dynamics_network = _Replica(DynamicsNetwork(
+            num_blocks, num_channels + 1, reduced_channels_reward, fc_reward_layers,
+            self.full_support_size, reduced_channels_reward * plane))
+        self.prediction_network = _Replica(PredictionNetwork(
+            action_space_size, num_blocks, num_channels, reduced_channels_value,
+            reduced_channels_policy, fc_value_layers, fc_policy_layers, self.full_support_size,
+            reduced_channels_value * plane, reduced_channels_policy * plane))
+
+    def prediction(self, encoded_state):
+        return self.prediction_network(encoded_state)
+
+    def representation(self, observation):
+        raw = self.representation_network(observation)
+        shifted, span = _unit_rescale(raw, (2, 3))  # per (sample, channel) over the board
+        return shifted / span
+
+    def dynamics(self, encoded_state, action, out_state=None):
+        b, _, h, w = encoded_state.shape
+        plane = (action.to(encoded_state.dtype) / self.action_space_size)[:, :, None, None]
+        x = torch.cat((encoded_state, plane.expand(b, 1, h, w)), dim=1)
+        raw, reward = self.dynamics_network(x)
+        shifted, span = _unit_rescale(raw, (2, 3))
+        return torch.div(shifted, span, out=out_state), reward
+
+    def initial_inference(self, observation):
+        encoded_state = self.representation(observation)
+        policy_logits, value = self.prediction(encoded_state)
+        reward = self._zero_reward_logits(observation.shape[0], observation.device)
+        return value, reward, policy_logits, encoded_state
+
+    def recurrent_inference(self, encoded_state, action, out_state=None):
+        next_state, reward = self.dynamics(encoded_state, action, out_state)
+        policy_logits, value = self.prediction(next_state)
+        return value, reward, policy_logits, next_state
+
+
+# ------------------------------------------------------------------------------------------------
+_SUPPORT_CACHE = {}
+
+
+def support_to_scalar(logits, support_size):
+    """Categorical -> scalar, reference models.py:641-662 (same fp32 operation order)."""
+    key = (support_size, logits.device, logits.dtype)
+    support = _SUPPORT_CACHE.get(key)
+    if support is None:
+        support = torch.arange(-support_size, support_size + 1, device=logits.device).to(logits.dtype)
+        _SUPPORT_CACHE[key] = support
+    probabilities = torch.softmax(logits, dim=1)
+    x = torch.sum(support.expand(probabilities.shape) * probabilities, dim=1, keepdim=True)
+    return torch.sign(x) * (((torch.sqrt(1 + 4 * 0.001 * (torch.abs(x) + 1 + 0.001)) - 1)
+                             / (2 * 0.001)) ** 2 - 1)
+
+
+def scalar_to_support(x, support_size):
+    """Scalar -> two-hot categorical target, reference models.py:665-685 (training side; kept so
+    trainer code that imports it from this module keeps working)."""
+    x = torch.sign(x) * (torch.sqrt(torch.abs(x) + 1) - 1) + 0.001 * x
+    x = torch.clamp(x, -support_size, support_size)
+    low = x.floor()
+    frac = x - low
+    out = torch.zeros(x.shape[0], x.shape[1], 2 * support_size + 1, device=x.device)
+    out.scatter_(2, (low + support_size).long().unsqueeze(-1), (1 - frac).unsqueeze(-1))
+    upper = low + support_size + 1
+    overflow = 2 * support_size < upper
+    frac = frac.masked_fill(overflow, 0.0)
+    upper = upper.masked_fill(overflow, 0.0)
+    out.scatter_(2, upper.long().unsqueeze(-1), frac.unsqueeze(-1))
+    return out

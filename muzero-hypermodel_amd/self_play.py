@@ -1,0 +1,497 @@
+"""Drop-in for the reference's self_play.py: SelfPlay, MCTS, Node, GameHistory, MinMaxStats.
+
+Same class names, method names, signatures and return values (reference self_play.py:11-568), so
+`muzero.py`-style orchestration, `diagnose_model.py`-style inspection and the replay buffer / trainer
+keep working -- but the search itself runs on the MI355X:
+
+  * `MCTS(config).run(...)` drives the HIP engine (engine.BatchedMCTS, one tree) and returns a `Node`
+    tree materialised from the device pools plus the same `extra_info` dict;
+  * `SelfPlay` is a plain class (no Ray): `.play_game`, `.continuous_self_play`, `.close_game`,
+    `.select_opponent_action` and the static `.select_action`;
+  * `BatchedSelfPlay` is the MI355X-native way to use the engine: E games in lock step, one actor per
+    GPU, each env on the RNG stream of reference worker `config.seed + e`.
+
+Randomness: the reference uses numpy's global legacy generator for everything.  The single-tree
+facade hands that global state to the engine's stream before a search and hands it back afterwards
+(`numpy.random.get_state/set_state`), so a run interleaves with any other user of `numpy.random`
+(games, expert agents) exactly as the reference does.
+"""
+import math
+import time
+
+import numpy
+import torch
+
+from . import _native, models
+from .engine import BatchedMCTS
+
+
+class SelfPlay:
+    """Plays games with MCTS at every move and hands them to the replay buffer
+    (reference self_play.py:11-246)."""
+
+    def __init__(self, initial_checkpoint, Game, config, seed):
+        self.config = config
+        self.game = Game(seed)
+
+        # Fix random generator seed (self_play.py:22-23)
+        numpy.random.seed(seed)
+        torch.manual_seed(seed)
+
+        self.model = models.MuZeroNetwork(self.config)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.to(torch.device("cuda" if torch.cuda.is_available() else "cpu"))
+        self.model.eval()
+        self._mcts = None
+
+    def _searcher(self):
+        if self._mcts is None:
+            self._mcts = MCTS(self.config)
+        return self._mcts
+
+    def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False):
+        """Game loop (self_play.py:31-108).  `shared_storage` / `replay_buffer` are any objects with
+        `get_info` / `set_info` / `save_game` methods (called directly: there is no Ray here)."""
+        while (shared_storage.get_info("training_step") < self.config.training_steps
+               and not shared_storage.get_info("terminate")):
+            self.model.set_weights(shared_storage.get_info("weights"))
+
+            if not test_mode:
+                game_history = self.play_game(
+                    self.config.visit_softmax_temperature_fn(
+                        trained_steps=shared_storage.get_info("training_step")),
+                    self.config.temperature_threshold, False, "self", 0)
+                replay_buffer.save_game(game_history, shared_storage)
+            else:
+                # Take the best action (no exploration) in test mode
+                game_history = self.play_game(
+                    0, self.config.temperature_threshold, False,
+                    "self" if len(self.config.players) == 1 else self.config.opponent,
+                    self.config.muzero_player)
+                shared_storage.set_info({
+                    "episode_length": len(game_history.action_history) - 1,
+                    "total_reward": sum(game_history.reward_history),
+                    "mean_value": numpy.mean([value for value in game_history.root_values if value]),
+                })
+                if 1 < len(self.config.players):
+                    mine = self.config.muzero_player
+                    shared_storage.set_info({
+                        "muzero_reward": sum(
+                            reward for i, reward in enumerate(game_history.reward_history)
+                            if game_history.to_play_history[i - 1] == mine),
+                        "opponent_reward": sum(
+                            reward for i, reward in enumerate(game_history.reward_history)
+                            if game_history.to_play_history[i - 1] != mine),
+                    })
+
+            # Managing the self-play / training ratio
+            if not test_mode and self.config.self_play_delay:
+                time.sleep(self.config.self_play_delay)
+            if not test_mode and self.config.ratio:
+                while (shared_storage.get_info("training_step")
+                       / max(1, shared_storage.get_info("num_played_steps")) < self.config.ratio
+                       and shared_storage.get_info("training_step") < self.config.training_steps
+                       and not shared_storage.get_info("terminate")):
+                    time.sleep(0.5)
+
+        self.close_game()
+
+    def play_game(self, temperature, temperature_threshold, render, opponent, muzero_player):
+        """One game, MCTS at every move (self_play.py:110-184)."""
+        game_history = GameHistory()
+        observation = self.game.reset()
+        game_history.action_history.append(0)
+        game_history.observation_history.append(observation)
+        game_history.reward_history.append(0)
+        game_history.to_play_history.append(self.game.to_play())
+
+        done = False
+        if render:
+            self.game.render()
+
+        with torch.no_grad():
+            while not done and len(game_history.action_history) <= self.config.max_moves:
+                shape = numpy.array(observation).shape
+                assert len(shape) == 3, (
+                    f"Observation should be 3 dimensionnal instead of {len(shape)} dimensionnal. "
+                    f"Got observation of shape: {shape}")
+                assert shape == self.config.observation_shape, (
+                    "Observation should match the observation_shape defined in MuZeroConfig. "
+                    f"Expected {self.config.observation_shape} but got {shape}.")
+                stacked_observations = game_history.get_stacked_observations(
+                    -1, self.config.stacked_observations)
+
+                # Choose the action
+                if opponent == "self" or muzero_player == self.game.to_play():
+                    root, mcts_info = self._searcher().run(
+                        self.model, stacked_observations, self.game.legal_actions(),
+                        self.game.to_play(), True)
+                    action = self.select_action(
+                        root,
+                        temperature
+                        if not temperature_threshold
+                        or len(game_history.action_history) < temperature_threshold
+                        else 0)
+                    if render:
+                        print(f'Tree depth: {mcts_info["max_tree_depth"]}')
+                        print(f"Root value for player {self.game.to_play()}: {root.value():.2f}")
+                else:
+                    action, root = self.select_opponent_action(opponent, stacked_observations)
+
+                observation, reward, done = self.game.step(action)
+
+                if render:
+                    print(f"Played action: {self.game.action_to_string(action)}")
+                    self.game.render()
+
+                game_history.store_search_statistics(root, self.config.action_space)
+
+                # Next batch
+                game_history.action_history.append(action)
+                game_history.observation_history.append(observation)
+                game_history.reward_history.append(reward)
+                game_history.to_play_history.append(self.game.to_play())
+
+        return game_history
+
+    def close_game(self):
+        self.game.close()
+        if self._mcts is not None:
+            self._mcts.close()
+            self._mcts = None
+
+    def select_opponent_action(self, opponent, stacked_observations):
+        """Opponent move when evaluating MuZero (self_play.py:189-221)."""
+        if opponent == "human":
+            root, mcts_info = self._searcher().run(
+                self.model, stacked_observations, self.game.legal_actions(), self.game.to_play(), True)
+            print(f'Tree depth: {mcts_info["max_tree_depth"]}')
+            print(f"Root value for player {self.game.to_play()}: {root.value():.2f}")
+            print(f"Player {self.game.to_play()} turn. MuZero suggests "
+                  f"{self.game.action_to_string(self.select_action(root, 0))}")
+            return self.game.human_to_action(), root
+        elif opponent == "expert":
+            return self.game.expert_agent(), None
+        elif opponent == "random":
+            assert self.game.legal_actions(), (
+                f"Legal actions should not be an empty array. Got {self.game.legal_actions()}.")
+            assert set(self.game.legal_actions()).issubset(set(self.config.action_space)), (
+                "Legal actions should be a subset of the action space.")
+            return numpy.random.choice(self.game.legal_actions()), None
+        else:
+            raise NotImplementedError(
+                'Wrong argument: "opponent" argument should be "self", "human", "expert" or "random"')
+
+    @staticmethod
+    def select_action(node, temperature):
+        """Sample the played action from the root's visit counts (self_play.py:223-246).
+
+        Uses the engine's numpy-legacy generator on numpy's global state, so the draw (and the number
+        of random words consumed) is the reference's."""
+        visit_counts = numpy.array([child.visit_count for child in node.children.values()], dtype="int32")
+        actions = [action for action in node.children.keys()]
+        if temperature == 0:
+            return actions[numpy.argmax(visit_counts)]
+        rng = _native.HostRng(0)
+        rng.set_state(numpy.random.get_state())
+        slot = rng.select_action(visit_counts, temperature)
+        numpy.random.set_state(rng.get_state())
+        return actions[slot]
+
+
+# Game independent
+class MCTS:
+    """Monte-Carlo tree search (self_play.py:250-431), executed by the HIP engine.
+
+    `run` keeps the reference signature.  `select_child`, `ucb_score` and `backpropagate` are kept
+    for callers that drive a search by hand on `Node` objects (diagnose-style tooling); they are
+    host-side conveniences and are not used by `run`."""
+
+    def __init__(self, config):
+        self.config = config
+        self._engine = None
+
+    def _get_engine(self, device):
+        if self._engine is None:
+            self._engine = BatchedMCTS(self.config, 1, device=device, seeds=[0])
+        return self._engine
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def run(self, model, observation, legal_actions, to_play, add_exploration_noise,
+            override_root_with=None):
+        """Search from `observation`; returns (root Node, {"max_tree_depth", "root_predicted_value"})."""
+        if override_root_with:
+            raise NotImplementedError(
+                "override_root_with is not supported by the device engine: trees live in HIP pools and "
+                "are rebuilt per search (the reference itself only uses it from diagnose_model.py)")
+        device = next(model.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("MCTS.run needs the model on a HIP device; the engine has no CPU fallback")
+        assert legal_actions, f"Legal actions should not be an empty array. Got {legal_actions}."
+        assert set(legal_actions).issubset(set(self.config.action_space)), (
+            "Legal actions should be a subset of the action space.")
+        engine = self._get_engine(device)
+        engine.set_rng_state(0, numpy.random.get_state())
+        obs = torch.tensor(numpy.asarray(observation)).float().unsqueeze(0)
+        stats = engine.search(model, obs, [list(legal_actions)], [to_play], add_exploration_noise)
+        numpy.random.set_state(engine.get_rng_state(0))
+
+        root = Node._from_engine(engine, list(legal_actions), to_play, len(self.config.players))
+        extra_info = {
+            "max_tree_depth": int(stats["max_tree_depth"][0]),
+            "root_predicted_value": float(stats["root_predicted_value"][0]),
+        }
+        return root, extra_info
+
+    def select_child(self, node, min_max_stats):
+        """Child with the highest UCB score, ties broken like the reference (self_play.py:364-379)."""
+        scored = [(self.ucb_score(node, child, min_max_stats), action)
+                  for action, child in node.children.items()]
+        top = max(score for score, _ in scored)
+        action = numpy.random.choice([action for score, action in scored if score == top])
+        return action, node.children[action]
+
+    def ucb_score(self, parent, child, min_max_stats):
+        """Prior exploration bonus + normalised value (self_play.py:381-405)."""
+        c = self.config
+        pb_c = math.log((parent.visit_count + c.pb_c_base + 1) / c.pb_c_base) + c.pb_c_init
+        pb_c *= math.sqrt(parent.visit_count) / (child.visit_count + 1)
+        score = pb_c * child.prior
+        if child.visit_count > 0:
+            q = child.value() if len(c.players) == 1 else -child.value()
+            score += min_max_stats.normalize(child.reward + c.discount * q)
+        return score
+
+    def backpropagate(self, search_path, value, to_play, min_max_stats):
+        """Propagate a leaf evaluation to the root (self_play.py:407-431)."""
+        n_players = len(self.config.players)
+        if n_players > 2:
+            raise NotImplementedError("More than two player mode not implemented.")
+        gamma = self.config.discount
+        for node in reversed(search_path):
+            if n_players == 1:
+                node.value_sum += value
+                node.visit_count += 1
+                min_max_stats.update(node.reward + gamma * node.value())
+                value = node.reward + gamma * value
+            else:
+                mine = node.to_play == to_play
+                node.value_sum += value if mine else -value
+                node.visit_count += 1
+                min_max_stats.update(node.reward + gamma * -node.value())
+                value = (-node.reward if mine else node.reward) + gamma * value
+
+
+class Node:
+    """Search-tree node with the reference's attributes (self_play.py:434-477).  Nodes returned by
+    `MCTS.run` are views materialised from the engine's device pools after the search."""
+
+    def __init__(self, prior):
+        self.visit_count = 0
+        self.to_play = -1
+        self.prior = prior
+        self.value_sum = 0
+        self.children = {}
+        self.hidden_state = None
+        self.reward = 0
+
+    def expanded(self):
+        return len(self.children) > 0
+
+    def value(self):
+        if self.visit_count == 0:
+            return 0
+        return self.value_sum / self.visit_count
+
+    def expand(self, actions, to_play, reward, policy_logits, hidden_state):
+        """Give the node children with softmax priors over `actions` (self_play.py:452-466)."""
+        self.to_play = to_play
+        self.reward = reward
+        self.hidden_state = hidden_state
+        priors = torch.softmax(torch.tensor([policy_logits[0][a] for a in actions]), dim=0).tolist()
+        for action, p in zip(actions, priors):
+            self.children[action] = Node(p)
+
+    def add_exploration_noise(self, dirichlet_alpha, exploration_fraction):
+        """Mix Dirichlet noise into the children's priors (self_play.py:468-477)."""
+        actions = list(self.children.keys())
+        noise = numpy.random.dirichlet([dirichlet_alpha] * len(actions))
+        frac = exploration_fraction
+        for a, n in zip(actions, noise):
+            self.children[a].prior = self.children[a].prior * (1 - frac) + n * frac
+
+    @classmethod
+    def _from_engine(cls, engine, legal_actions, to_play, n_players, env=0):
+        """Rebuild the whole tree of `env` from the exported child-record pools."""
+        tree = engine.export_tree(env)
+        stats = engine.stats
+        state_shape = engine.state_shape
+
+        def hidden(k):
+            return engine.pool[k, env].view(1, *state_shape)
+
+        root = cls(0)
+        root.visit_count = int(stats["root_visits"][env])
+        root.value_sum = float(stats["root_value_sum"][env])
+        root.to_play = to_play
+        root.reward = 0.0
+        root.hidden_state = hidden(0)
+        stack = [(root, 0, 0)]  # (node, expanded-node index, tree depth)
+        while stack:
+            node, k, depth = stack.pop()
+            actions = legal_actions if k == 0 else range(engine.A)
+            for slot, action in enumerate(actions):
+                child = cls(float(tree["prior"][k, slot]))
+                child.visit_count = int(tree["visits"][k, slot])
+                child.value_sum = float(tree["value_sum"][k, slot])
+                child.reward = float(tree["reward"][k, slot])
+                node.children[action] = child
+                ck = int(tree["child_node"][k, slot])
+                if ck >= 0:
+                    child.to_play = (to_play + depth + 1) % n_players
+                    child.hidden_state = hidden(ck)
+                    stack.append((child, ck, depth + 1))
+        return root
+
+
+class GameHistory:
+    """What is stored of a self-play game (self_play.py:480-548)."""
+
+    def __init__(self):
+        self.observation_history = []
+        self.action_history = []
+        self.reward_history = []
+        self.to_play_history = []
+        self.child_visits = []
+        self.root_values = []
+        self.reanalysed_predicted_root_values = None
+        # For PER
+        self.priorities = None
+        self.game_priority = None
+
+    def store_search_statistics(self, root, action_space):
+        """Turn the root's visit counts into a policy target (self_play.py:497-512)."""
+        if root is None:
+            self.root_values.append(None)
+            return
+        total = sum(child.visit_count for child in root.children.values())
+        self.child_visits.append(
+            [root.children[a].visit_count / total if a in root.children else 0 for a in action_space])
+        self.root_values.append(root.value())
+
+    def get_stacked_observations(self, index, num_stacked_observations):
+        """Observation at `index` followed by the previous observations, each with the plane of the
+        action that led out of it; zero planes before the start of the game (self_play.py:514-548)."""
+        index = index % len(self.observation_history)
+        planes = [self.observation_history[index].copy()]
+        like_plane = numpy.ones_like(planes[0][0])
+        for past in range(index - 1, index - num_stacked_observations - 1, -1):
+            if past >= 0:
+                planes.append(self.observation_history[past])
+                planes.append([like_plane * self.action_history[past + 1]])
+            else:
+                planes.append(numpy.zeros_like(self.observation_history[index]))
+                planes.append([numpy.zeros_like(planes[0][0])])
+        return numpy.concatenate(planes) if len(planes) > 1 else planes[0]
+
+
+class MinMaxStats:
+    """Running min / max of the values seen in one search tree (self_play.py:551-568)."""
+
+    def __init__(self):
+        self.maximum = -float("inf")
+        self.minimum = float("inf")
+
+    def update(self, value):
+        self.maximum = max(self.maximum, value)
+        self.minimum = min(self.minimum, value)
+
+    def normalize(self, value):
+        if self.maximum > self.minimum:
+            # only once both bounds have been set
+            return (value - self.minimum) / (self.maximum - self.minimum)
+        return value
+
+
+class BatchedSelfPlay:
+    """E games in lock step on one GPU: the MI355X-native actor.
+
+    Env e plays with `Game(seed + e)` and the RNG stream of reference worker `seed + e`
+    (muzero.py:170-178), so with E == 1 it reproduces `SelfPlay.play_game`, and with E > 1 each env
+    reproduces what the reference's e-th Ray worker would have played with the same weights.
+    Finished games are handed to `on_game(env_index, GameHistory)` and their env restarts at once.
+    """
+
+    def __init__(self, initial_checkpoint, Game, config, seed, num_envs, device=None, use_graph=True):
+        self.config = config
+        self.E = int(num_envs)
+        self.games = [Game(seed + e) for e in range(self.E)]
+        self.device = torch.device(device if device is not None else "cuda")
+        torch.manual_seed(seed)
+        self.model = models.MuZeroNetwork(config)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.to(self.device)
+        self.model.eval()
+        self.engine = BatchedMCTS(config, self.E, device=self.device,
+                                  seeds=[seed + e for e in range(self.E)], use_graph=use_graph)
+        self.histories = [None] * self.E
+        self.observations = [None] * self.E
+        self.moves_played = 0
+        self.games_finished = 0
+        for e in range(self.E):
+            self._restart(e)
+
+    def _restart(self, e):
+        gh = GameHistory()
+        obs = self.games[e].reset()
+        gh.action_history.append(0)
+        gh.observation_history.append(obs)
+        gh.reward_history.append(0)
+        gh.to_play_history.append(self.games[e].to_play())
+        self.histories[e] = gh
+        self.observations[e] = obs
+
+    def set_weights(self, weights):
+        self.model.set_weights(weights)
+
+    def step(self, temperature, temperature_threshold=None, on_game=None):
+        """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
+        cfg = self.config
+        stacked = numpy.stack([
+            self.histories[e].get_stacked_observations(-1, cfg.stacked_observations)
+            for e in range(self.E)]).astype(numpy.float32)
+        legal = [self.games[e].legal_actions() for e in range(self.E)]
+        to_play = [self.games[e].to_play() for e in range(self.E)]
+        self.engine.search(self.model, stacked, legal, to_play, True)
+        temps = numpy.array([
+            temperature if not temperature_threshold
+            or len(self.histories[e].action_history) < temperature_threshold else 0
+            for e in range(self.E)], dtype=numpy.float64)
+        actions, _ = self.engine.sample_actions(temps)
+        child_visits, root_values = self.engine.search_statistics()
+        for e in range(self.E):
+            gh = self.histories[e]
+            action = int(actions[e])
+            observation, reward, done = self.games[e].step(action)
+            gh.child_visits.append([float(v) if a in legal[e] else 0 for a, v in enumerate(child_visits[e])])
+            gh.root_values.append(float(root_values[e]))
+            gh.action_history.append(action)
+            gh.observation_history.append(observation)
+            gh.reward_history.append(reward)
+            gh.to_play_history.append(self.games[e].to_play())
+            self.observations[e] = observation
+            if done or len(gh.action_history) > cfg.max_moves:
+                self.games_finished += 1
+                if on_game is not None:
+                    on_game(e, gh)
+                self._restart(e)
+        self.moves_played += self.E
+
+    def close(self):
+        for g in self.games:
+            g.close()
+        self.engine.close()

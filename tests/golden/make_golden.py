@@ -568,6 +568,38 @@ def g10_reference_speed(ctx):
          cpu=numpy.array(open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0]))
 
 
+def g11_envs(ctx):
+    """Board-game plugin behaviour: random legal playouts of the reference envs with, at every
+    position, the observation, legal list, to_play and the expert agent's move under a fixed seed."""
+    import games.connect4 as c4
+    import games.tictactoe as ttt
+    for name, mod, n_games in (("tictactoe", ttt, 40), ("connect4", c4, 25)):
+        rs = numpy.random.RandomState(2024)
+        rows = dict(game=[], step=[], action=[], reward=[], done=[], to_play=[], expert=[],
+                    n_legal=[], legal=[], obs=[])
+        A = len(mod.MuZeroConfig().action_space)
+        for g in range(n_games):
+            game = mod.Game(g)
+            obs = game.reset()
+            t, done, action, reward = 0, False, -1, 0
+            while True:
+                legal = list(game.legal_actions())
+                rows["game"].append(g); rows["step"].append(t); rows["action"].append(action)
+                rows["reward"].append(reward); rows["done"].append(done)
+                rows["to_play"].append(game.to_play()); rows["n_legal"].append(len(legal))
+                rows["legal"].append(legal + [-1] * (A - len(legal)))
+                rows["obs"].append(numpy.asarray(obs, dtype="float32"))
+                if done:
+                    rows["expert"].append(-1)
+                    break
+                numpy.random.seed(1000 + 31 * g + t)
+                rows["expert"].append(int(game.expert_agent()))
+                action = int(rs.choice(legal))
+                obs, reward, done = game.step(action)
+                t += 1
+        save(f"g11_{name}_env", **{k: numpy.array(v) for k, v in rows.items()})
+
+
 def make_configs():
     import games.tictactoe as ttt
     import games.connect4 as c4
@@ -588,7 +620,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed]
+       g9_stacked, g10_reference_speed, g11_envs]
 
 
 def main():

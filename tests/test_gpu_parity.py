@@ -1,0 +1,460 @@
+"""Parity tests proper: the HIP engine, called through the C ABI, against the oracle and the golden
+fixtures recorded from the reference.  Needs an MI355X (`pytest -m gpu`).
+
+  injected mode  network outputs replayed -> every integer and every fp64 statistic BIT-EXACT
+  native mode    PyTorch-ROCm inference   -> logits / priors within 1e-5, decoded values within 3e-5
+                 relative (fp32 conditioning of the inverse value transform, see
+                 tests/test_oracle_mcts.py), policy targets identical wherever paths are identical
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from parity_helpers import (cartpole_model_and_weights, fixture_config, load_golden, make_search_config,
+                            random_streams, run_injected_on_engine, run_injected_on_oracle,
+                            streams_from_fixture, synthetic_model)
+
+pytestmark = pytest.mark.gpu
+
+TRACE_FILES = ["g4_cartpole_traces", "g5_tictactoe_traces", "g5_connect4_traces", "g5_cartpole_ties_traces"]
+EXACT_KEYS = ["noise", "visits", "child_value_sum", "child_prior", "child_reward", "root_value_sum",
+              "root_visits", "max_tree_depth", "min_max", "sim_depth", "sim_actions", "sim_ties",
+              "child_visits_target", "root_value_target", "action"]
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return importlib.import_module("muzero-hypermodel_amd.engine")
+
+
+@pytest.fixture(scope="module")
+def models_mod(pkg):
+    return importlib.import_module("muzero-hypermodel_amd.models")
+
+
+def games(name):
+    return importlib.import_module(f"muzero-hypermodel_amd.games.{name}")
+
+
+def assert_exact(got, want, keys=EXACT_KEYS, where=""):
+    for key in keys:
+        assert np.array_equal(got[key], want[key]), f"{where}{key} differs"
+
+
+# ---- injected mode: bit-exact ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", TRACE_FILES)
+def test_injected_traces_bit_exact_vs_reference_and_oracle(eng, oracle, name):
+    fx = load_golden(name)
+    T = len(fx["seed"])
+    idx = list(range(T))
+    temps = fx["temperature"].tolist()
+    got = run_injected_on_engine(eng, None, fx, idx, temperature=temps)
+    want = run_injected_on_oracle(oracle, fx, idx=idx, temperature=temps)
+    assert_exact(got, want, where=f"{name} vs oracle: ")
+    # and directly against what the reference recorded
+    A, S = int(fx["cfg_A"]), int(fx["cfg_S"])
+    for key in ("noise", "visits", "child_value_sum", "child_prior", "child_reward"):
+        assert np.array_equal(got[key], fx[key]), key
+    assert np.array_equal(got["root_value_sum"], fx["root_value_sum"])
+    assert np.array_equal(got["max_tree_depth"], fx["max_tree_depth"])
+    assert np.array_equal(got["min_max"][:, 0], fx["mms_min"]) and np.array_equal(got["min_max"][:, 1], fx["mms_max"])
+    assert np.array_equal(got["sim_depth"], fx["sim_depth"])
+    assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, :S])
+    assert np.array_equal(got["sim_ties"], fx["sim_ties"][:, :, :S])
+    assert np.array_equal(got["child_visits_target"], fx["child_visits_target"])
+    assert np.array_equal(got["root_value_target"], fx["root_value_target"])
+    assert np.array_equal(got["action"], fx["action_T"])
+    # RNG stream accounting: Dirichlet words (host) + tie-break words (device) == reference's count
+    dirichlet_words = want["rng_words_run"] - got["tie_break_words"]
+    assert (dirichlet_words > 0).all()
+    assert np.array_equal(got["depth_sum"], fx["sim_depth"].sum(axis=1))
+
+
+def test_injected_batching_independence(eng):
+    """4096 trees = the 32 CartPole traces tiled 128x: every copy must be identical to the first."""
+    fx = load_golden("g4_cartpole_traces")
+    got = run_injected_on_engine(eng, None, fx, list(range(32)), record_paths=False, repeat=128)
+    assert got["all_equal"]
+    assert np.array_equal(got["visits"], fx["visits"])
+    assert np.array_equal(got["root_value_sum"], fx["root_value_sum"])
+
+
+@pytest.mark.parametrize("A,S,players,discount,ties", [
+    (1, 12, 1, 0.997, False), (2, 50, 1, 0.997, True), (3, 40, 2, 1, False), (4, 50, 1, 0.997, False),
+    (7, 200, 2, 1, False), (9, 25, 2, 1, True), (16, 30, 1, 0.9, False), (33, 40, 2, 0.95, True),
+    (64, 40, 1, 0.997, False), (65, 30, 2, 1, False), (121, 60, 2, 1, True), (256, 20, 1, 0.997, False)])
+def test_injected_random_streams_vs_oracle(eng, oracle, A, S, players, discount, ties):
+    """Configurations no golden trace covers (all lane-group widths, the A > 64 chunked path, long
+    searches, exact-tie storms): engine vs oracle, bit-exact."""
+    cfg = make_search_config(A, S, players, discount)
+    T = 24
+    streams = random_streams(T, A, S, seed=1000 + A, n_players=players, ties=ties)
+    temps = [[1.0, 0.5, 0.25, 0.0][t % 4] for t in range(T)]
+    got = run_injected_on_engine(eng, cfg, streams, temperature=temps)
+    want = run_injected_on_oracle(oracle, cfg, streams, temperature=temps)
+    assert_exact(got, want, where=f"A={A} S={S}: ")
+    if ties:
+        assert got["tie_break_words"].sum() > T       # the device RNG really was exercised
+
+
+def test_mt19937_twist_on_device(eng, oracle):
+    """All-equal priors force a tie-break at every level: > 624 words per search, so the device
+    generator regenerates its state mid-search; the host mirror must stay in step for the next move."""
+    A, S, T = 2, 400, 6
+    cfg = make_search_config(A, S, 1, 1.0)
+    streams = random_streams(T, A, S, seed=5, n_players=1)
+    streams["priors"][:] = 0.5
+    streams["root_priors"][:] = 0.0
+    for t in range(T):
+        streams["legal"][t] = [0, 1]
+        streams["root_priors"][t] = [0.5, 0.5]
+    streams["value"][:] = 0.0
+    streams["reward"][:] = 0.0
+    engine = eng.BatchedMCTS(cfg, T, seeds=streams["seeds"])
+    got1 = run_injected_on_engine(eng, cfg, streams, engine=engine, record_paths=False)
+    assert (got1["tie_break_words"] > 624).all()
+    engine.close()
+    want1 = run_injected_on_oracle(oracle, cfg, streams)
+    assert_exact(got1, want1, keys=["noise", "visits", "root_value_sum", "action", "max_tree_depth"])
+
+
+def test_two_consecutive_moves_keep_rng_in_step(eng, oracle):
+    """Move 2 starts from the RNG state move 1 left behind (Dirichlet + tie-breaks + action sample)."""
+    fx = load_golden("g5_cartpole_ties_traces")
+    idx = list(range(8))
+    streams = streams_from_fixture(fx, idx)
+    cfg = fixture_config(fx)
+    engine = eng.BatchedMCTS(cfg, len(idx), seeds=streams["seeds"])
+    S = cfg.num_simulations
+
+    def one_move():
+        engine.begin_search(streams["legal"], streams["to_play"], True)
+        noise = engine.noise.copy()
+        engine.expand_roots_injected(streams["root_reward"], streams["root_priors"])
+        for s in range(S):
+            engine.select(gather=False)
+            engine.expand_backup_injected(streams["value"][:, s], streams["reward"][:, s], streams["priors"][:, s])
+        st = {k: v.copy() for k, v in engine.readout().items()}
+        actions, _ = engine.sample_actions(1.0)
+        return noise, st, actions
+
+    moves = [one_move(), one_move()]
+    engine.close()
+    ocfg = oracle.config_from_fixture(fx)
+    for t in range(len(idx)):
+        rng = oracle.Rng(streams["seeds"][t])
+        for noise, st, actions in moves:
+            tree = oracle.Tree(ocfg)
+            n = len(streams["legal"][t])
+            want_noise = tree.reset(rng, streams["legal"][t], streams["to_play"][t], float(streams["root_reward"][t]),
+                                    root_priors=streams["root_priors"][t][:n])
+            tree.simulate(rng, value=streams["value"][t], reward=streams["reward"][t], priors=streams["priors"][t])
+            ost = tree.root_stats()
+            assert np.array_equal(noise[t, :n], want_noise[:n])
+            assert np.array_equal(st["visits"][t, :n], ost["visits"])
+            assert st["root_value_sum"][t] == ost["root_value_sum"]
+            slot = oracle.select_action(rng, ost["visits"], 1.0)
+            assert actions[t] == streams["legal"][t][slot]
+
+
+def test_inactive_envs_are_left_alone(eng, oracle):
+    fx = load_golden("g5_tictactoe_traces")
+    idx = list(range(12))
+    streams = streams_from_fixture(fx, idx)
+    cfg = fixture_config(fx)
+    off = {1, 5, 6}
+    for t in off:
+        streams["legal"][t] = []
+    engine = eng.BatchedMCTS(cfg, len(idx), seeds=streams["seeds"])
+    got = run_injected_on_engine(eng, cfg, streams, engine=engine, temperature=fx["temperature"][:12].tolist())
+    states_off = {t: engine.get_rng_state(t) for t in off}
+    engine.close()
+    for t in range(len(idx)):
+        if t in off:
+            assert got["visits"][t].sum() == 0 and got["action"][t] == -1 and got["root_visits"][t] == 0
+            fresh = oracle.Rng(streams["seeds"][t]).get_numpy_state()
+            assert np.array_equal(states_off[t][1], fresh[1]) and states_off[t][2] == fresh[2]
+        else:
+            assert np.array_equal(got["visits"][t], fx["visits"][t])
+            assert got["action"][t] == fx["action_T"][t]
+
+
+def test_plugin_contract_errors(eng):
+    cfg = make_search_config(9, 5, 2, 1)
+    engine = eng.BatchedMCTS(cfg, 2)
+    with pytest.raises(AssertionError, match="subset of the action space"):
+        engine.begin_search([[0, 9], [1]], [0, 0], True)
+    with pytest.raises(AssertionError, match="subset of the action space"):
+        engine.begin_search([list(range(10)), [1]], [0, 0], True)
+    with pytest.raises(RuntimeError, match="before begin_search|before expand_roots"):
+        engine.select()
+    engine.close()
+    with pytest.raises(NotImplementedError, match="More than two player"):
+        eng.BatchedMCTS(make_search_config(2, 5, 3, 1), 2)
+
+
+# ---- device decode kernels vs the reference's torch outputs -----------------------------------------
+def test_support_to_scalar_and_softmax_kernels(eng):
+    fx = load_golden("g1_support_to_scalar")
+    E = 64
+    cfg = make_search_config(2, 3, 1, 0.997, support=10)
+    engine = eng.BatchedMCTS(cfg, E)
+    logits = torch.from_numpy(fx["logits21"]).cuda()
+    policy = torch.from_numpy(np.random.RandomState(0).standard_normal((E, 2)).astype(np.float32)).cuda()
+    engine.begin_search([[0, 1]] * E, [0] * E, False)
+    engine.expand_roots(logits, None, policy, torch.zeros(E, 4, device="cuda"))
+    st = engine.readout()
+    np.testing.assert_allclose(st["root_predicted_value"], fx["out21"][:, 0].astype(np.float64), rtol=1e-5, atol=1e-5)
+    want_priors = torch.softmax(policy.cpu(), dim=1).numpy().astype(np.float64)
+    np.testing.assert_allclose(st["child_prior"], want_priors, rtol=0, atol=1e-6)
+    engine.close()
+    # F = 601 (atari.py support 300)
+    cfg = make_search_config(4, 3, 1, 0.997, support=300)
+    engine = eng.BatchedMCTS(cfg, 8)
+    engine.begin_search([[0, 1, 2, 3]] * 8, [0] * 8, False)
+    engine.expand_roots(torch.from_numpy(fx["logits601"]).cuda(), None, torch.zeros(8, 4, device="cuda"),
+                        torch.zeros(8, 4, device="cuda"))
+    st = engine.readout()
+    np.testing.assert_allclose(st["root_predicted_value"], fx["out601"][:, 0].astype(np.float64), rtol=1e-4, atol=2e-4)
+    engine.close()
+
+
+# ---- native mode: PyTorch-ROCm inference + HIP tree kernels -------------------------------------------
+def native_vs_fixture(eng, model, config, fx, idx, min_agree):
+    T = len(idx)
+    engine = eng.BatchedMCTS(config, T, seeds=[int(fx["seed"][i]) for i in idx])
+    engine.set_debug_ties(True)
+    obs = np.stack([fx["obs"][i] for i in idx])
+    legal = [fx["legal"][i][: int(fx["n_legal"][i])].tolist() for i in idx]
+    to_play = [int(fx["to_play"][i]) for i in idx]
+    S = config.num_simulations
+    paths = np.full((T, S, S), -1, np.int32)
+    with torch.no_grad():
+        value, reward, policy, hidden = model.initial_inference(torch.from_numpy(obs).cuda())
+        np.testing.assert_allclose(policy.cpu().numpy(), np.stack([fx["root_policy_logits"][i] for i in idx]),
+                                   rtol=1e-5, atol=1e-5)
+        engine.begin_search(legal, to_play, True)
+        engine.expand_roots(value, reward.contiguous(), policy, hidden)
+        for s in range(S):
+            engine._simulate_once(model)
+            _, actions, _ = engine.last_paths()
+            paths[:, s] = actions
+    st = engine.readout()
+    cv, rv = engine.search_statistics()
+    temps = [float(fx["temperature"][i]) for i in idx]
+    actions, _ = engine.sample_actions(temps)
+    engine.close()
+    same = 0
+    for t, i in enumerate(idx):
+        n = int(fx["n_legal"][i])
+        assert st["visits"][t].sum() == S and st["root_visits"][t] == S
+        assert abs(st["root_predicted_value"][t] - fx["root_predicted_value"][i]) <= 3e-5 * max(1, abs(fx["root_predicted_value"][i]))
+        assert np.array_equal(engine.noise[t, :n], fx["noise"][i][:n])          # host RNG: exact
+        if not np.array_equal(paths[t], fx["sim_actions"][i][:, :S]):
+            continue
+        same += 1
+        assert np.array_equal(st["visits"][t], fx["visits"][i])
+        assert np.array_equal(cv[t], fx["child_visits_target"][i])              # policy target: exact
+        assert abs(rv[t] - fx["root_value_target"][i]) <= 3e-5 * max(1.0, abs(fx["root_value_target"][i]))
+        np.testing.assert_allclose(st["child_prior"][t, :n], fx["child_prior"][i][:n], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(st["child_value_sum"][t, :n], fx["child_value_sum"][i][:n], rtol=3e-5, atol=1e-4)
+        assert actions[t] == fx["action_T"][i]
+    assert same >= min_agree * T, f"identical-path rate {same}/{T}"
+    return same / T
+
+
+def test_native_cartpole_vs_reference(eng, models_mod):
+    config = games("cartpole").MuZeroConfig()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g4_cartpole_traces")
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.8)
+
+
+def test_native_tictactoe_vs_reference(eng, models_mod):
+    config = games("tictactoe").MuZeroConfig()
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    fx = load_golden("g5_tictactoe_traces")
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.7)
+
+
+def test_native_connect4_vs_reference(eng, models_mod):
+    config = games("connect4").MuZeroConfig()
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    fx = load_golden("g5_connect4_traces")
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.5)
+
+
+def test_gpu_network_outputs_vs_reference_fixtures(models_mod):
+    for name, loader in (("cartpole", "fc"), ("tictactoe", "res"), ("connect4", "res"), ("atari84", "res")):
+        if name == "atari84":
+            config = games("breakout").atari84_config()
+        else:
+            config = games(name).MuZeroConfig()
+        if loader == "fc":
+            model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+            fx = load_golden("g2_fc_inference")
+        else:
+            model, _ = synthetic_model(models_mod, config, "cuda")
+            fx = load_golden(f"g3_{name}_inference")
+        with torch.no_grad():
+            v0, r0, p0, h0 = model.initial_inference(torch.from_numpy(fx["obs"]).cuda())
+            v1, r1, p1, h1 = model.recurrent_inference(torch.from_numpy(fx["init_hidden"]).cuda(),
+                                                       torch.from_numpy(fx["actions"]).cuda())
+        for got, key in ((v0, "init_value"), (p0, "init_policy"), (h0, "init_hidden"), (v1, "rec_value"),
+                         (r1, "rec_reward"), (p1, "rec_policy"), (h1, "rec_hidden")):
+            np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=2e-5, atol=2e-5, err_msg=f"{name}:{key}")
+
+
+def test_graph_replay_equals_eager(eng, models_mod):
+    """The hipGraph-captured simulation loop must give bit-identical trees to eager launches."""
+    config = games("cartpole").MuZeroConfig()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    E = 256
+    rs = np.random.RandomState(3)
+    obs = [rs.uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32) for _ in range(4)]
+    results = {}
+    for mode in (False, True):
+        engine = eng.BatchedMCTS(config, E, use_graph=mode)
+        out = []
+        for o in obs:
+            st = engine.search(model, o, [[0, 1]] * E, [0] * E, True)
+            acts, _ = engine.sample_actions(1.0)
+            out.append((st["visits"].copy(), st["root_value_sum"].copy(), st["child_value_sum"].copy(), acts.copy()))
+        assert (engine._graph is not None) == mode
+        results[mode] = out
+        engine.close()
+    for a, b in zip(results[False], results[True]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_full_size_invariants_cartpole_4096(eng, models_mod):
+    """BASELINE config #2 (4096 envs x 50 sims): size-independent properties + run-to-run determinism."""
+    config = games("cartpole").MuZeroConfig()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    E, S = 4096, config.num_simulations
+    obs = np.random.RandomState(123).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        engine = eng.BatchedMCTS(config, E, use_graph=False)
+        st = {k: v.copy() for k, v in engine.search(model, obs, [[0, 1]] * E, [0] * E, True).items()}
+        cv, rv = engine.search_statistics()
+        tree = engine.export_tree(17)
+        engine.close()
+        runs.append((st, cv, rv, tree))
+    st, cv, rv, tree = runs[0]
+    assert (st["visits"].sum(axis=1) == S).all() and (st["root_visits"] == S).all()
+    assert (st["max_tree_depth"] >= 1).all() and (st["max_tree_depth"] <= S).all()
+    assert (st["depth_sum"] >= S).all()
+    np.testing.assert_allclose(cv.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    assert (st["min_max"][:, 0] <= st["min_max"][:, 1]).all()
+    np.testing.assert_allclose(st["child_prior"].sum(axis=1), 1.0, rtol=0, atol=1e-6)
+    # whole-tree consistency of one env: every expanded node's visits = 1 + sum of its children's
+    visits, child = tree["visits"], tree["child_node"]
+    for k in range(S + 1):
+        for a in range(2):
+            ck = child[k, a]
+            if ck >= 0:
+                assert visits[k, a] == 1 + visits[ck].sum()
+    assert sorted(int(c) for c in child.reshape(-1) if c >= 0) == list(range(1, S + 1))
+    for (a_st, a_cv, a_rv, _), (b_st, b_cv, b_rv, _) in [(runs[0], runs[1])]:
+        for key in a_st:
+            assert np.array_equal(a_st[key], b_st[key]), key
+        assert np.array_equal(a_rv, b_rv)
+
+
+# ---- the drop-in facade -------------------------------------------------------------------------------
+def test_mcts_run_facade_matches_reference_trace(eng, models_mod, pkg):
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    config = games("cartpole").MuZeroConfig()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g4_cartpole_traces")
+    mcts = sp.MCTS(config)
+    hits = 0
+    for i in range(8):
+        np.random.seed(int(fx["seed"][i]))
+        root, info = mcts.run(model, fx["obs"][i], [0, 1], 0, True)
+        assert set(info) == {"max_tree_depth", "root_predicted_value"}
+        assert root.visit_count == config.num_simulations and root.hidden_state.shape == (1, 8)
+        assert sum(c.visit_count for c in root.children.values()) == config.num_simulations
+        assert abs(info["root_predicted_value"] - fx["root_predicted_value"][i]) <= 3e-5 * abs(fx["root_predicted_value"][i])
+        action = sp.SelfPlay.select_action(root, float(fx["temperature"][i]))
+        gh = sp.GameHistory()
+        gh.store_search_statistics(root, config.action_space)
+        if [c.visit_count for c in root.children.values()] == fx["visits"][i].tolist():
+            hits += 1
+            assert info["max_tree_depth"] == fx["max_tree_depth"][i]
+            assert [c.prior for c in root.children.values()] == pytest.approx(fx["child_prior"][i].tolist(), abs=1e-6)
+            assert gh.child_visits[0] == fx["child_visits_target"][i].tolist()
+            assert abs(gh.root_values[0] - fx["root_value_target"][i]) <= 3e-5 * abs(fx["root_value_target"][i])
+            assert action == fx["action_T"][i]
+        # deep structure: expanded children carry hidden states and children of their own
+        for child in root.children.values():
+            if child.visit_count > 0:
+                assert child.expanded() and child.hidden_state is not None and child.to_play == 0
+    mcts.close()
+    assert hits >= 6
+    with pytest.raises(AssertionError, match="should not be an empty array"):
+        sp.MCTS(config).run(model, fx["obs"][0], [], 0, True)
+
+
+def test_self_play_games_vs_reference_g6(eng, models_mod, pkg):
+    """SelfPlay.play_game on TicTacToe with the synthetic weights: trajectories recorded from the
+    reference (seeds 0-3 self-play, expert / random opponents, temperature threshold)."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    ttt = games("tictactoe")
+    config = ttt.MuZeroConfig()
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    fx = load_golden("g6_tictactoe_games")
+    full, total = 0, int(fx["n_runs"])
+    for i in range(total):
+        seed, temp, thr, opp, mzp = fx[f"run{i}_args"]
+        opponent = {0: "self", 1: "expert", 2: "random"}[int(opp)]
+        actor = sp.SelfPlay({"weights": weights}, ttt.Game, config, int(seed))
+        gh = actor.play_game(float(temp), None if thr < 0 else int(thr), False, opponent, int(mzp))
+        actor.close_game()
+        ref_actions = fx[f"run{i}_actions"].tolist()
+        # the first move depends only on the root search: it must agree
+        assert gh.action_history[0] == 0 and gh.to_play_history[0] == 0
+        n = min(len(ref_actions), len(gh.action_history))
+        agree = 0
+        while agree < n and gh.action_history[agree] == ref_actions[agree]:
+            agree += 1
+        assert agree >= 2, f"run {i}: diverged at the very first move"
+        if agree == len(ref_actions) == len(gh.action_history):
+            full += 1
+            assert gh.reward_history == fx[f"run{i}_rewards"].tolist()
+            assert gh.to_play_history == fx[f"run{i}_to_play"].tolist()
+            got_cv = np.array(gh.child_visits, dtype=np.float64).reshape(-1, 9)
+            assert np.array_equal(got_cv, fx[f"run{i}_child_visits"])
+            got_rv = np.array([np.nan if v is None else v for v in gh.root_values])
+            np.testing.assert_allclose(got_rv, fx[f"run{i}_root_values"], rtol=3e-5, atol=1e-5, equal_nan=True)
+            assert int(np.random.randint(0, 2**31 - 1)) == int(fx[f"run{i}_rng_next_word"])
+    assert full >= total - 2, f"only {full}/{total} games reproduced move for move"
+
+
+def test_batched_self_play_matches_single_env_actor(eng, models_mod, pkg):
+    """E lock-step envs: env e must play exactly the game reference worker `seed + e` plays."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    ttt = games("tictactoe")
+    config = ttt.MuZeroConfig()
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E = 4
+    finished = {}
+    batched = sp.BatchedSelfPlay({"weights": weights}, ttt.Game, config, 0, E, use_graph=False)
+    while len(finished) < E:
+        batched.step(1.0, None, on_game=lambda e, gh: finished.setdefault(e, gh))
+    batched.close()
+    fx = load_golden("g6_tictactoe_games")
+    for e in range(E):
+        single = sp.SelfPlay({"weights": weights}, ttt.Game, config, e)
+        gh = single.play_game(1.0, None, False, "self", 0)
+        single.close_game()
+        assert finished[e].action_history == gh.action_history
+        assert finished[e].reward_history == gh.reward_history
+        assert np.array_equal(np.array(finished[e].child_visits, dtype=float), np.array(gh.child_visits, dtype=float))
+        assert finished[e].root_values == gh.root_values
