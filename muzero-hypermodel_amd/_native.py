@@ -106,6 +106,10 @@ def load():
         raise NativeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The MCTS engine has no Python fallback.")
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  It must be the one already
+    # mapped when libmzmcts.so resolves its dependency: two HIP runtimes in one process do not see the
+    # same devices / streams.  Importing torch first guarantees that.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here == header / library out of sync

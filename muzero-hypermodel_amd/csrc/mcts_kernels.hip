@@ -173,6 +173,10 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
         }
         ++depth;
         if (sel_child < 0) break;  // reached a node that is not expanded yet
+        if (depth > sim) {         // cannot happen on a consistent tree (only sim+1 nodes are expanded);
+            if (j == 0) atomicOr(p.error_flag, 2);  // guarantees every wave leaves the loop regardless
+            break;
+        }
         k = sel_child;
         N = sel_visits;
         n_children = p.A;

@@ -532,7 +532,10 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
     MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipStreamSynchronize(stream));
     if (eng->h_error_flag[0] != 0)
-        return fail(eng, MZMCTS_ERR_INVALID, "device error flag set: a UCB score was NaN (no maximum to select)");
+        return fail(eng, MZMCTS_ERR_INVALID,
+                    (eng->h_error_flag[0] & 2) ? "device error flag set: tree links are inconsistent (descent ran past the "
+                                                 "number of expanded nodes)"
+                                               : "device error flag set: a UCB score was NaN (no maximum to select)");
 
     const int sims = eng->sim;
     int64_t depth_total = 0, active = 0;
