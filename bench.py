@@ -160,14 +160,34 @@ def roofline_leg(engine, one_step, steps, device):
                          "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
     d = kernels[dominant]
+    traffic, traffic_source = pmc_traffic(f"mz::{dominant}_kernel", engine.E)
     roofline = {"bound": "hbm", "kernel": f"mz::{dominant}_kernel", "achieved": d["achieved_GBs"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
-                "traffic": None, "avg_kernel_us": d["avg_us"], "mean_select_depth": mean_depth,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "avg_kernel_us": d["avg_us"], "mean_select_depth": mean_depth,
                 "algorithmic_bytes_per_simulation": bytes_sim,
                 "timing": "hip events on the launch stream, eager pass of the same steps "
                           "(the value-region replays a hipGraph, which events cannot subdivide)",
                 "working_set_bytes": engine.device_bytes()}
     return roofline, kernels
+
+
+def pmc_traffic(kernel, envs):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE need separate runs and cannot be collected from inside this process).  Raw counter
+    bytes, uncorrected -- see DESIGN.md section 5."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_e{envs}.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))["counters"]
+    total = 0.0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        hit = [v for k, v in data.get(counter, {}).items() if kernel in k]
+        if not hit:
+            return None, None
+        total += hit[0]["mean_KB_per_launch"] * 1024.0
+    return total, os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline_leg(config, w, seconds):

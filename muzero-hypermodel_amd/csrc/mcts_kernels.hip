@@ -11,6 +11,7 @@
 // libm table staged in LDS; ties are detected with == on the fp64 scores and broken with the
 // tree's MT19937 stream exactly as numpy.random.choice does.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -602,7 +603,21 @@ static inline int tree_grid(const TreeParams& p) {
 
 constexpr int kFuseGatherMaxFloats = 64;
 
-hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream) {
+// Launch with optional HIP events bound to the dispatch itself (hipExtLaunchKernel records the
+// kernel's own start / end timestamps into the events, so profiling-mode timings are kernel
+// durations, comparable with rocprofv3's, not launch-to-launch gaps).
+template <typename Kernel, typename... Args>
+static void launch_kernel(Kernel kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                          const LaunchTiming* timing, Args... args) {
+    if (timing && timing->start)
+        hipExtLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds), stream, timing->start, timing->stop, 0u,
+                              args...);
+    else
+        kernel<<<grid, block, lds, stream>>>(args...);
+}
+
+hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
+                         const LaunchTiming* timing) {
     const size_t lds = sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1);
     const int grid = tree_grid(p);
     const bool fuse = p.H <= kFuseGatherMaxFloats;
@@ -610,9 +625,11 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (fuse)
-            select_kernel<G, CH, true><<<dim3(grid), dim3(kThreads), lds, stream>>>(p, sim, hidden_out, action_out);
+            launch_kernel(select_kernel<G, CH, true>, dim3(grid), dim3(kThreads), lds, stream, timing, p, sim, hidden_out,
+                          action_out);
         else
-            select_kernel<G, CH, false><<<dim3(grid), dim3(kThreads), lds, stream>>>(p, sim, hidden_out, action_out);
+            launch_kernel(select_kernel<G, CH, false>, dim3(grid), dim3(kThreads), lds, stream, timing, p, sim, hidden_out,
+                          action_out);
     });
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
@@ -629,34 +646,35 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
                                const float* policy_logits, const float* root_hidden, const double* inj_reward,
                                const double* inj_priors, const double* noise, const uint32_t* rng_skip,
-                               bool injected, hipStream_t stream) {
+                               bool injected, hipStream_t stream, const LaunchTiming* timing) {
     const int grid = tree_grid(p);
     dispatch_group(p.A, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (injected)
-            expand_roots_kernel<G, CH, true><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-                p, value_logits, reward_logits, policy_logits, root_hidden, inj_reward, inj_priors, noise, rng_skip);
+            launch_kernel(expand_roots_kernel<G, CH, true>, dim3(grid), dim3(kThreads), 0, stream, timing, p, value_logits,
+                          reward_logits, policy_logits, root_hidden, inj_reward, inj_priors, noise, rng_skip);
         else
-            expand_roots_kernel<G, CH, false><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-                p, value_logits, reward_logits, policy_logits, root_hidden, inj_reward, inj_priors, noise, rng_skip);
+            launch_kernel(expand_roots_kernel<G, CH, false>, dim3(grid), dim3(kThreads), 0, stream, timing, p, value_logits,
+                          reward_logits, policy_logits, root_hidden, inj_reward, inj_priors, noise, rng_skip);
     });
     return hipGetLastError();
 }
 
 hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
                                 const float* policy_logits, const double* inj_value, const double* inj_reward,
-                                const double* inj_priors, bool injected, hipStream_t stream) {
+                                const double* inj_priors, bool injected, hipStream_t stream,
+                                const LaunchTiming* timing) {
     const int grid = tree_grid(p);
     dispatch_group(p.A, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (injected)
-            expand_backup_kernel<G, CH, true><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-                p, sim, value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors);
+            launch_kernel(expand_backup_kernel<G, CH, true>, dim3(grid), dim3(kThreads), 0, stream, timing, p, sim,
+                          value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors);
         else
-            expand_backup_kernel<G, CH, false><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-                p, sim, value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors);
+            launch_kernel(expand_backup_kernel<G, CH, false>, dim3(grid), dim3(kThreads), 0, stream, timing, p, sim,
+                          value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors);
     });
     return hipGetLastError();
 }

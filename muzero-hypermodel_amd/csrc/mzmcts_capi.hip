@@ -19,14 +19,16 @@
 #include "tree_layout.h"
 
 namespace mz {
-hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream);
+hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
+                         const LaunchTiming* timing);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
                                const float* policy_logits, const float* root_hidden, const double* inj_reward,
                                const double* inj_priors, const double* noise, const uint32_t* rng_skip,
-                               bool injected, hipStream_t stream);
+                               bool injected, hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
                                 const float* policy_logits, const double* inj_value, const double* inj_reward,
-                                const double* inj_priors, bool injected, hipStream_t stream);
+                                const double* inj_priors, bool injected, hipStream_t stream,
+                                const LaunchTiming* timing);
 hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t stream);
 hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
 }  // namespace mz
@@ -139,25 +141,23 @@ bool stream_is_capturing(hipStream_t s) {
     return st != hipStreamCaptureStatusNone;
 }
 
-// bracket a launch with HIP events on the launch stream (profiling mode, never while capturing)
+// In profiling mode (never while capturing) hand the launcher an event pair that HIP binds to the
+// kernel dispatch itself, so the elapsed time is the kernel's own duration.
 struct ProfScope {
-    mzmcts_engine* eng;
-    hipStream_t stream;
-    EventPair* pair = nullptr;
-    ProfScope(mzmcts_engine* e, hipStream_t s, int kind) : eng(e), stream(s) {
+    mz::LaunchTiming timing;
+    ProfScope(mzmcts_engine* eng, hipStream_t s, int kind) {
         if (!eng->profiling || stream_is_capturing(s)) return;
         if (eng->events_used == eng->events.size()) {
             EventPair np{};
             if (hipEventCreate(&np.begin) != hipSuccess || hipEventCreate(&np.end) != hipSuccess) return;
             eng->events.push_back(np);
         }
-        pair = &eng->events[eng->events_used++];
-        pair->kind = kind;
-        (void)hipEventRecord(pair->begin, stream);
+        EventPair& pair = eng->events[eng->events_used++];
+        pair.kind = kind;
+        timing.start = pair.begin;
+        timing.stop = pair.end;
     }
-    ~ProfScope() {
-        if (pair) (void)hipEventRecord(pair->end, stream);
-    }
+    const mz::LaunchTiming* get() const { return timing.start ? &timing : nullptr; }
 };
 
 void parallel_for(int n, int max_threads, const std::function<void(int, int)>& body) {
@@ -434,7 +434,7 @@ static int expand_roots_common(mzmcts_engine* eng, const float* value_logits, co
         ProfScope scope(eng, stream, kProfRoot);
         MZ_HIP(eng, mz::launch_expand_roots(eng->p, value_logits, reward_logits, policy_logits, root_hidden, inj_reward,
                                             inj_priors, eng->noise_this_search ? eng->d_noise : nullptr, eng->d_skip,
-                                            injected, stream));
+                                            injected, stream, scope.get()));
     }
     eng->roots_ready = true;
     eng->sim = 0;
@@ -462,7 +462,8 @@ int mzmcts_select(mzmcts_engine* eng, float* parent_hidden_out, int64_t* action_
     if (eng->sim >= eng->p.S) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select: all simulations already ran");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope scope(eng, stream, kProfSelect);
-    MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream));
+    MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream,
+                                  scope.get()));
     return MZMCTS_OK;
 }
 
@@ -480,7 +481,7 @@ int mzmcts_expand_backup(mzmcts_engine* eng, const float* value_logits, const fl
     {
         ProfScope scope(eng, stream, kProfBackup);
         MZ_HIP(eng, mz::launch_expand_backup(eng->p, eng->sim, value_logits, reward_logits, policy_logits, nullptr,
-                                             nullptr, nullptr, false, stream));
+                                             nullptr, nullptr, false, stream, scope.get()));
     }
     eng->sim += 1;
     return MZMCTS_OK;
@@ -496,7 +497,7 @@ int mzmcts_expand_backup_injected(mzmcts_engine* eng, const double* value, const
     {
         ProfScope scope(eng, stream, kProfBackup);
         MZ_HIP(eng, mz::launch_expand_backup(eng->p, eng->sim, nullptr, nullptr, nullptr, value, reward, priors, true,
-                                             stream));
+                                             stream, scope.get()));
     }
     eng->sim += 1;
     return MZMCTS_OK;

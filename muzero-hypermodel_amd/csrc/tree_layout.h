@@ -20,6 +20,8 @@
 // to_play is not stored: with players == range(P) the reference's virtual_to_play rotation
 // (self_play.py:332-335) makes it (root_to_play + tree_depth) mod P.
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include <cstdint>
 
 namespace mz {
@@ -72,5 +74,11 @@ struct TreeParams {
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// Optional pair of HIP events a launcher binds to the kernel dispatch (profiling mode).
+struct LaunchTiming {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
 
 }  // namespace mz
