@@ -56,6 +56,11 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--obs-sets", type=int, default=8)
+    ap.add_argument("--mode", choices=["fused", "lockstep"], default="fused",
+                    help="fused: whole move in one HIP launch (FC net in-kernel, trees in LDS); "
+                         "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
+    ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
+    ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
     return ap.parse_args()
 
 
@@ -73,20 +78,26 @@ def main():
     E, S, A = args.envs, config.num_simulations, len(config.action_space)
     w = load_golden("cartpole_weights")
     weights = {k: torch.from_numpy(w[k]) for k in w.files}
-    actor = actor_mod.SearchActor(config, weights, E, rank=rank, device=device, use_graph=not args.no_graph)
+    fused = args.mode == "fused"
+    group = args.group if args.group else (4 if fused else 0)
+    actor = actor_mod.SearchActor(config, weights, E, rank=rank, device=device, use_graph=not args.no_graph,
+                                  group_width=group, fused_fc=fused)
     engine, model = actor.engine, actor.model
+    engine.fused_hidden_in_lds = not args.hidden_in_hbm
 
     rs = np.random.RandomState(123 + rank)
     obs_sets = [torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).to(device)
                 for _ in range(args.obs_sets)]
-    legal = [[0, 1]] * E
-    to_play = [0] * E
+    legal = np.tile(np.arange(A, dtype=np.int32), (E, 1))
+    num_legal = np.full(E, A, dtype=np.int32)
+    to_play = np.zeros(E, dtype=np.int32)
+    temperature = np.ones(E, dtype=np.float64)
 
     def one_step(i):
         if world > 1 and args.bcast_every and i % args.bcast_every == 0:
             actor.refresh_weights(src=0)
-        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True)
-        engine.sample_actions(1.0)
+        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
+        engine.sample_actions(temperature)
 
     def barrier():
         if world > 1:
@@ -114,8 +125,12 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cartpole_fc_4096envs_x_50sims", "envs_per_gpu": E, "simulations": S,
-                   "actions": A, "network": "fullyconnected (reference checkpoint, fp32 inference)",
-                   "launch": "eager" if args.no_graph else "hipgraph", "parallelism": f"actors{world}",
+                   "actions": A,
+                   "network": "fullyconnected (reference checkpoint), fp32 inference "
+                              + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm"),
+                   "mode": args.mode, "lanes_per_tree": engine.group_width(),
+                   "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
+                   "parallelism": f"actors{world}",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
         "self_play_moves_per_sec": world * E * args.steps / elapsed,
     }
@@ -151,11 +166,14 @@ def roofline_leg(engine, one_step, steps, device):
     mean_depth = prof["select_depth_sum"] / sims
     bytes_sim = engine.algorithmic_bytes_per_simulation(mean_depth)
     kernels = {}
-    for name, ms_key, n_key in (("select", "select_ms", "select_launches"),
-                                ("expand_backup", "expand_backup_ms", "expand_backup_launches")):
-        launches = max(prof[n_key], 1)
-        avg_us = 1e3 * prof[ms_key] / launches
-        per_launch = bytes_sim[name] * engine.E
+    per_kernel = [("select", "select_ms", "select_launches", bytes_sim["select"] * engine.E),
+                  ("expand_backup", "expand_backup_ms", "expand_backup_launches", bytes_sim["expand_backup"] * engine.E),
+                  # one fused launch = S simulations of every tree: select + expand/backup bytes of all of them
+                  ("search_fused_fc", "fused_ms", "fused_launches", bytes_sim["total"] * engine.E * engine.S)]
+    for name, ms_key, n_key, per_launch in per_kernel:
+        if prof[n_key] == 0:
+            continue
+        avg_us = 1e3 * prof[ms_key] / prof[n_key]
         kernels[name] = {"avg_us": avg_us, "launches": prof[n_key], "algorithmic_bytes_per_launch": per_launch,
                          "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
@@ -166,8 +184,8 @@ def roofline_leg(engine, one_step, steps, device):
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_kernel_us": d["avg_us"], "mean_select_depth": mean_depth,
                 "algorithmic_bytes_per_simulation": bytes_sim,
-                "timing": "hip events on the launch stream, eager pass of the same steps "
-                          "(the value-region replays a hipGraph, which events cannot subdivide)",
+                "timing": "HIP events bound to the kernel dispatch (hipExtLaunchKernel) on the launch stream, "
+                          "over a second pass of the same steps",
                 "working_set_bytes": engine.device_bytes()}
     return roofline, kernels
 

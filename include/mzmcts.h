@@ -56,7 +56,8 @@ typedef struct mzmcts_config {
     int32_t support_size;    /* config.support_size; F = 2*support_size+1 logits              */
     int32_t hidden_floats;   /* H: fp32 values per hidden state (0 = engine keeps no states)  */
     int32_t device;          /* HIP device ordinal                                            */
-    int32_t reserved;
+    int32_t group_width;     /* lanes of a wavefront per tree: 0 = auto (pow2 >= min(A,64)); or a power of two
+                                in [auto, 64] to give each tree more lanes (fused FC search)           */
     double discount;                  /* config.discount                                      */
     double pb_c_base;                 /* config.pb_c_base                                     */
     double pb_c_init;                 /* config.pb_c_init                                     */
@@ -86,8 +87,8 @@ typedef struct mzmcts_root_stats {
 
 /* HIP-event timings accumulated while profiling is on (bench.py roofline leg). */
 typedef struct mzmcts_profile {
-    double select_ms, expand_backup_ms, root_ms; /* summed kernel-bracket times           */
-    int64_t select_launches, expand_backup_launches, root_launches;
+    double select_ms, expand_backup_ms, root_ms, fused_ms; /* summed kernel durations      */
+    int64_t select_launches, expand_backup_launches, root_launches, fused_launches;
     int64_t select_depth_sum;  /* sum over launches and trees of the select depth (d-bar) */
     int64_t simulations;       /* tree-simulations executed (launches x active trees)     */
 } mzmcts_profile;
@@ -187,6 +188,40 @@ int mzmcts_set_debug_ties(mzmcts_engine *engine, int32_t enabled);
  * child_node[k*A+slot] = index of that child's own expanded node or -1.  Blocking. */
 int mzmcts_export_tree(mzmcts_engine *engine, int32_t env, int32_t *visits, double *value_sum,
                        double *prior, double *reward, int32_t *child_node, void *stream);
+
+/* ---- fully-connected networks in-kernel --------------------------------------------------------
+ * MuZeroFullyConnectedNetwork's inference half (models.py:128-195) as HIP device code, so that a whole
+ * move -- initial_inference, root expansion and all S x (select, recurrent_inference, expand, backup)
+ * -- runs in ONE launch with every tree, its hidden states, the activations and the weights resident
+ * in LDS (trees are independent, so nothing synchronises between them).  Residual networks keep the
+ * lock-step path above with any external inference engine. */
+typedef struct mzmcts_fc_desc {
+    int32_t observation_floats; /* flattened (stacked) observation size                              */
+    int32_t encoding_size;      /* config.encoding_size == hidden_floats                             */
+    int32_t n_hidden[5];        /* hidden-layer counts of: representation, dynamics, reward, policy, value */
+    int32_t hidden[5][3];       /* their widths (fc_*_layers), at most 3 hidden layers each          */
+} mzmcts_fc_desc;
+/* weights: dev f32[n_weights], every Linear's weight then bias in state_dict order (representation,
+ * dynamics_encoded_state, dynamics_reward, prediction_policy, prediction_value).  The pointer is
+ * retained (e.g. the flat buffer an RCCL weight broadcast lands in): refreshing it refreshes the net. */
+int mzmcts_fc_configure(mzmcts_engine *engine, const mzmcts_fc_desc *desc, const float *weights,
+                        int64_t n_weights);
+/* Lock-step form of the same device code (one launch per [E,.] batch), outputs as the torch modules':
+ *   initial:   observations dev f32[E,obs]        recurrent: hidden dev f32[E,enc], action dev i64[E]
+ *   value_logits / reward_logits dev f32[E,F], policy_logits dev f32[E,A], hidden_out dev f32[E,enc] */
+int mzmcts_fc_initial_inference(mzmcts_engine *engine, const float *observations, float *value_logits,
+                                float *reward_logits, float *policy_logits, float *hidden_out, void *stream);
+int mzmcts_fc_recurrent_inference(mzmcts_engine *engine, const float *hidden, const int64_t *action,
+                                  float *value_logits, float *reward_logits, float *policy_logits,
+                                  float *hidden_out, void *stream);
+/* Whole search in one launch (after mzmcts_begin_search): observations dev f32[E,obs].
+ * hidden_in_lds: 1 = keep hidden states in LDS too when they fit, 0 = read them back from the HBM pool.
+ * Leaves the engine in the same state as expand_roots + S x (select, expand_backup): readout,
+ * sample_actions, search_statistics and export_tree work unchanged. */
+int mzmcts_search_fused_fc(mzmcts_engine *engine, const float *observations, int32_t hidden_in_lds,
+                           void *stream);
+/* Dynamic LDS bytes per workgroup the fused kernel would use (0 = not configured / does not fit). */
+int64_t mzmcts_fused_lds_bytes(mzmcts_engine *engine, int32_t hidden_in_lds);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);

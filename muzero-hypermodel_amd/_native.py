@@ -24,7 +24,7 @@ class MzConfig(ctypes.Structure):
     _fields_ = [("num_envs", ctypes.c_int32), ("num_actions", ctypes.c_int32),
                 ("num_simulations", ctypes.c_int32), ("num_players", ctypes.c_int32),
                 ("support_size", ctypes.c_int32), ("hidden_floats", ctypes.c_int32),
-                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("group_width", ctypes.c_int32),
                 ("discount", ctypes.c_double), ("pb_c_base", ctypes.c_double),
                 ("pb_c_init", ctypes.c_double), ("root_dirichlet_alpha", ctypes.c_double),
                 ("root_exploration_fraction", ctypes.c_double), ("hidden_pool", c_void)]
@@ -40,9 +40,15 @@ class MzRootStats(ctypes.Structure):
 
 class MzProfile(ctypes.Structure):
     _fields_ = [("select_ms", ctypes.c_double), ("expand_backup_ms", ctypes.c_double),
-                ("root_ms", ctypes.c_double), ("select_launches", ctypes.c_int64),
-                ("expand_backup_launches", ctypes.c_int64), ("root_launches", ctypes.c_int64),
+                ("root_ms", ctypes.c_double), ("fused_ms", ctypes.c_double),
+                ("select_launches", ctypes.c_int64), ("expand_backup_launches", ctypes.c_int64),
+                ("root_launches", ctypes.c_int64), ("fused_launches", ctypes.c_int64),
                 ("select_depth_sum", ctypes.c_int64), ("simulations", ctypes.c_int64)]
+
+
+class MzFcDesc(ctypes.Structure):
+    _fields_ = [("observation_floats", ctypes.c_int32), ("encoding_size", ctypes.c_int32),
+                ("n_hidden", ctypes.c_int32 * 5), ("hidden", (ctypes.c_int32 * 3) * 5)]
 
 
 # name -> (restype, argtypes); every symbol include/mzmcts.h declares
@@ -74,6 +80,11 @@ PROTOTYPES = {
     "mzmcts_set_debug_ties": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_export_tree": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_f64_p, c_f64_p, c_f64_p,
                                           c_i32_p, c_void]),
+    "mzmcts_fc_configure": (ctypes.c_int, [c_void, ctypes.POINTER(MzFcDesc), c_void, ctypes.c_int64]),
+    "mzmcts_fc_initial_inference": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "mzmcts_fc_recurrent_inference": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "mzmcts_search_fused_fc": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void]),
+    "mzmcts_fused_lds_bytes": (ctypes.c_int64, [c_void, ctypes.c_int32]),
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),

@@ -46,7 +46,8 @@ class SearchActor:
     """Model replica + BatchedMCTS engine for one GPU's shard of envs (search only: envs are supplied
     by the caller as observation / legal-action batches, e.g. bench.py's synthetic rollouts)."""
 
-    def __init__(self, config, weights, envs_per_rank, rank=0, device=None, use_graph=True):
+    def __init__(self, config, weights, envs_per_rank, rank=0, device=None, use_graph=True, group_width=0,
+                 fused_fc=False):
         self.config = config
         self.rank = rank
         self.device = torch.device(device if device is not None else "cuda")
@@ -56,7 +57,11 @@ class SearchActor:
         self.model.eval()
         self.flat = FlatWeights(self.model)
         self.engine = BatchedMCTS(config, envs_per_rank, device=self.device,
-                                  seeds=shard_seeds(config.seed, rank, envs_per_rank), use_graph=use_graph)
+                                  seeds=shard_seeds(config.seed, rank, envs_per_rank), use_graph=use_graph,
+                                  group_width=group_width)
+        if fused_fc:
+            # the fused kernel reads the same flat buffer the RCCL broadcast lands in
+            self.engine.configure_fused_fc(self.model, self.flat)
         self.weight_version = 0
 
     def refresh_weights(self, src=0):

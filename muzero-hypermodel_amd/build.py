@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
 SOURCES = ["mcts_kernels.hip", "mzmcts_capi.hip"]
-HEADERS = ["np_legacy_rng.h", "tree_layout.h", os.path.join("..", "..", "include", "mzmcts.h")]
+HEADERS = ["np_legacy_rng.h", "tree_layout.h", "tree_device.h", "fc_net_device.h", os.path.join("..", "..", "include", "mzmcts.h")]
 
 # -ffp-contract=off is part of the numerical contract: the fp64 UCB / backup arithmetic must not be
 # fused into FMAs or it stops being bit-identical to the reference's Python floats.

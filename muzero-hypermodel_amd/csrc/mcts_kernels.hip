@@ -1,67 +1,66 @@
-// mcts_kernels.hip -- batched MCTS tree kernels for CDNA4 (gfx950, wave64).
+// mcts_kernels.hip -- batched MCTS kernels for CDNA4 (gfx950, wave64).
 //
-// Mapping: a tree is owned by a group of G = pow2 >= min(A,64) adjacent lanes of ONE wavefront,
-// one lane per child (lanes loop when A > 64).  A 64-thread workgroup (one wave) carries 64/G
-// trees; tree -> workgroup is identical in every kernel, so a tree's blocks are re-touched from the
-// same XCD (workgroups are dealt round-robin over the 8 XCDs) and stay in that XCD's L2.
+// Mapping: a tree is owned by a group of G adjacent lanes of ONE wavefront (G = pow2 >= min(A,64),
+// or wider on request), one lane per child (lanes loop when A > 64).  A 64-thread workgroup (one
+// wave) carries 64/G trees; tree -> workgroup is identical in every kernel, so a tree's blocks are
+// re-touched from the same XCD (workgroups are dealt round-robin over the 8 XCDs) and stay in that
+// XCD's L2.
+//
+// Two execution shapes share the device functions of tree_device.h / fc_net_device.h:
+//   lock-step   select_kernel -> (any inference engine, e.g. PyTorch-ROCm) -> expand_backup_kernel,
+//               tree in HBM; general networks.
+//   fused       search_fused_fc_kernel: one launch per MOVE for fully-connected networks -- every
+//               workgroup keeps its trees (child blocks, path, hidden states, activations) and the
+//               network weights in LDS and runs root inference + all S simulations without leaving
+//               the CU; trees never synchronise with each other because they are independent.
 //
 // Arithmetic contract (bit-exact with the reference's Python floats): every UCB / backup
-// operation is an IEEE fp64 +,-,*,/ in the reference's order (this file is compiled with
-// -ffp-contract=off, so nothing is fused); log/sqrt of the parent visit count come from a host
-// libm table staged in LDS; ties are detected with == on the fp64 scores and broken with the
-// tree's MT19937 stream exactly as numpy.random.choice does.
+// operation is an IEEE fp64 +,-,*,/ in the reference's order (compiled with -ffp-contract=off, so
+// nothing is fused); log/sqrt of the parent visit count come from a host libm table staged in LDS;
+// ties are detected with == on the fp64 scores and broken with the tree's MT19937 stream exactly as
+// numpy.random.choice does.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <type_traits>
 
+#include "fc_net_device.h"
 #include "np_legacy_rng.h"
+#include "tree_device.h"
 #include "tree_layout.h"
 
 namespace mz {
 
+// Diagnostic build only (-DMZ_STAMPS, tools/stamp_fused.py): per-phase cycle sums of the fused kernel,
+// written to a debug buffer that nothing else reads.  The production library never defines it.
+#ifdef MZ_STAMPS
+__device__ unsigned long long g_stamp_sums[8];
+#define MZ_STAMP_DECL unsigned long long stamp_prev = __builtin_readcyclecounter(), stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MZ_STAMP(slot)                                                   \
+    do {                                                                 \
+        const unsigned long long now__ = __builtin_readcyclecounter();   \
+        stamp_acc[slot] += now__ - stamp_prev;                           \
+        stamp_prev = now__;                                              \
+    } while (0)
+#define MZ_STAMP_FLUSH                                                                        \
+    do {                                                                                      \
+        if (threadIdx.x == 0)                                                                 \
+            for (int s__ = 0; s__ < 8; ++s__) atomicAdd(&g_stamp_sums[s__], stamp_acc[s__]);  \
+    } while (0)
+#else
+#define MZ_STAMP_DECL
+#define MZ_STAMP(slot)
+#define MZ_STAMP_FLUSH
+#endif
+
 constexpr int kThreads = 64;   // one wavefront per workgroup
 constexpr int kMaxChunks = 4;  // A <= 256
-constexpr int kStageLevels = 16;
 
-template <int G>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, G));
-    return v;
-}
-template <int G>
-__device__ __forceinline__ float group_maxf(float v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, G));
-    return v;
-}
-template <int G>
-__device__ __forceinline__ float group_sumf(float v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = v + __shfl_xor(v, m, G);
-    return v;
-}
-
-__device__ __forceinline__ uint8_t* block_ptr(const TreeParams& p, int k, int e) {
-    return p.blocks + (static_cast<size_t>(k) * p.E + e) * p.block_stride;
-}
-
-// self_play.py:381-405 ucb_score, one child.
-__device__ __forceinline__ double ucb_score(double pb_log, double pb_sqrt, const ChildStats& s,
-                                            const ChildLinks& l, double discount, bool two_player,
-                                            double mn, double mx) {
-    double pb_c = pb_log;
-    pb_c = pb_c * (pb_sqrt / static_cast<double>(l.visits + 1));
-    const double prior_score = pb_c * s.prior;
-    double value_score = 0.0;
-    if (l.visits > 0) {
-        double q = s.value_sum / static_cast<double>(l.visits);
-        if (two_player) q = -q;
-        const double v = static_cast<double>(l.reward) + discount * q;
-        value_score = (mx > mn) ? (v - mn) / (mx - mn) : v;
+__device__ __forceinline__ void stage_pbc_table(double* table, const TreeParams& p) {
+    for (int i = threadIdx.x; i <= p.S; i += kThreads) {
+        table[i] = p.pbc_log[i];
+        table[p.S + 1 + i] = p.pbc_sqrt[i];
     }
-    return prior_score + value_score;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -72,10 +71,7 @@ template <int G, int CH, bool FUSE_GATHER>
 __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim, float* __restrict__ hidden_out,
                                                           int64_t* __restrict__ action_out) {
     extern __shared__ double pbc_table[];  // [2][S+1]
-    for (int i = threadIdx.x; i <= p.S; i += kThreads) {
-        pbc_table[i] = p.pbc_log[i];
-        pbc_table[p.S + 1 + i] = p.pbc_sqrt[i];
-    }
+    stage_pbc_table(pbc_table, p);
     __syncthreads();
 
     constexpr int kTrees = kThreads / G;
@@ -83,8 +79,8 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
     const int j = threadIdx.x % G;
     const int group_base = threadIdx.x - j;  // lane of the group leader inside the wave
     if (e >= p.E) return;
-    int n_children = p.root_children[e];
-    if (n_children == 0) {  // inactive tree: keep the batch row defined
+    const int n_root = p.root_children[e];
+    if (n_root == 0) {  // inactive tree: keep the batch row defined
         if (j == 0) {
             p.path_len[e] = 0;
             p.leaf_parent[e] = 0;
@@ -95,105 +91,25 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
         return;
     }
 
-    const bool two_player = p.P == 2;
+    const GlobalTree tree = global_tree(p, e);
     const MinMax mm = p.min_max[e];
-    uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
     int32_t mt_pos = (j == 0) ? p.mt_pos[e] : 0;
     uint32_t words = 0;
-
-    int k = 0;        // expanded-node index of the current parent
-    int N = sim;      // its visit count: the root has been visited once per finished simulation
-    int depth = 0;
-    int slot = 0;
-    for (;;) {
-        const uint8_t* blk = block_ptr(p, k, e);
-        const ChildStats* stats = reinterpret_cast<const ChildStats*>(blk);
-        const ChildLinks* links = reinterpret_cast<const ChildLinks*>(blk + p.links_offset);
-        const double pb_log = pbc_table[N];
-        const double pb_sqrt = pbc_table[p.S + 1 + N];
-
-        double score[CH];
-        ChildLinks lk[CH];
-        double best = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int child = c * G + j;
-            score[c] = -INFINITY;
-            lk[c] = ChildLinks{0.f, 0, -1, 0};
-            if (child < n_children) {
-                const ChildStats st = stats[child];
-                lk[c] = links[child];
-                score[c] = ucb_score(pb_log, pb_sqrt, st, lk[c], p.discount, two_player, mm.minimum, mm.maximum);
-                best = fmax(best, score[c]);
-            }
-        }
-        best = group_max<G>(best);
-
-        // tie list in child order (self_play.py:372-378)
-        unsigned long long tie_mask[CH];
-        int n_ties = 0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const bool is_max = (c * G + j < n_children) && (score[c] == best);
-            const unsigned long long ballot = __ballot(is_max);
-            tie_mask[c] = (G == 64) ? ballot : ((ballot >> group_base) & ((1ull << G) - 1ull));
-            n_ties += __popcll(tie_mask[c]);
-        }
-        int pick = 0;
-        if (n_ties > 1) {
-            uint32_t r = 0;
-            if (j == 0) r = mt_below(key, &mt_pos, static_cast<uint32_t>(n_ties), &words);
-            pick = static_cast<int>(__shfl(r, 0, G));
-        } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
-            if (j == 0) atomicOr(p.error_flag, 1);
-            tie_mask[0] = 1ull;
-        }
-        int sel_visits = 0, sel_child = -1;
-        {
-            int remaining = pick;
-            bool found = false;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                unsigned long long m = tie_mask[c];
-                const int cnt = __popcll(m);
-                if (!found && remaining < cnt) {
-                    for (int i = 0; i < remaining; ++i) m &= m - 1ull;
-                    const int bit = __ffsll(static_cast<long long>(m)) - 1;
-                    slot = c * G + bit;
-                    sel_visits = __shfl(lk[c].visits, bit, G);
-                    sel_child = __shfl(lk[c].child_node, bit, G);
-                    found = true;
-                } else if (!found) {
-                    remaining -= cnt;  // (found / remaining are uniform across the group's lanes)
-                }
-            }
-        }
-        if (j == 0) {
-            p.path[static_cast<size_t>(depth) * p.E + e] = (k << 16) | slot;
-            if (p.path_ties) p.path_ties[static_cast<size_t>(depth) * p.E + e] = n_ties;
-        }
-        ++depth;
-        if (sel_child < 0) break;  // reached a node that is not expanded yet
-        if (depth > sim) {         // cannot happen on a consistent tree (only sim+1 nodes are expanded);
-            if (j == 0) atomicOr(p.error_flag, 2);  // guarantees every wave leaves the loop regardless
-            break;
-        }
-        k = sel_child;
-        N = sel_visits;
-        n_children = p.A;
-    }
-
+    const Descent d = descend<G, CH>(tree, pbc_table, p.S, p.A, sim, n_root, mm, p.discount, p.P == 2,
+                                     p.mt_key + static_cast<size_t>(e) * kMtN, mt_pos, words, j, group_base,
+                                     p.path_ties ? p.path_ties + e : nullptr, p.E, p.error_flag);
     if (j == 0) {
-        p.path_len[e] = depth;
-        p.leaf_parent[e] = k;
+        p.path_len[e] = d.depth;
+        p.leaf_parent[e] = d.parent;
         if (words) {
             p.mt_pos[e] = mt_pos;
             p.tie_words[e] += words;
         }
-        if (action_out) action_out[e] = (depth == 1) ? p.root_action[static_cast<size_t>(e) * p.A + slot] : slot;
+        if (action_out)
+            action_out[e] = (d.depth == 1) ? p.root_action[static_cast<size_t>(e) * p.A + d.slot] : d.slot;
     }
     if (FUSE_GATHER && hidden_out) {
-        const float* src = p.hidden + (static_cast<size_t>(k) * p.E + e) * p.H;
+        const float* src = p.hidden + (static_cast<size_t>(d.parent) * p.E + e) * p.H;
         float* dst = hidden_out + static_cast<size_t>(e) * p.H;
         if ((p.H & 3) == 0) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -205,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
     }
 }
 
-// Stand-alone gather for large hidden states (ResNet planes): one workgroup per tree row chunk,
+// Stand-alone gather for large hidden states (ResNet planes): one workgroup row per tree,
 // 16-byte lanes, fully coalesced on both sides.
 __global__ __launch_bounds__(256) void gather_hidden_kernel(TreeParams p, float* __restrict__ hidden_out) {
     const int e = blockIdx.x;
@@ -234,56 +150,29 @@ __global__ __launch_bounds__(256) void copy_slab_kernel(const float* __restrict_
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// models.py:641-662 support_to_scalar, fp32, torch's operation order; the F logits of one tree are
-// spread over the G lanes of its group.
-// -------------------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ float support_to_scalar_group(const float* __restrict__ logits, int F, int support, int j) {
-    float m = -INFINITY;
-    for (int i = j; i < F; i += G) m = fmaxf(m, logits[i]);
-    m = group_maxf<G>(m);
-    float s = 0.f;
-    for (int i = j; i < F; i += G) s += expf(logits[i] - m);
-    s = group_sumf<G>(s);
-    const float inv = 1.0f / s;
-    float acc = 0.f;
-    for (int i = j; i < F; i += G) acc += static_cast<float>(i - support) * (expf(logits[i] - m) * inv);
-    const float x = group_sumf<G>(acc);
-    const float u = (fabsf(x) + 1.0f) + 0.001f;
-    const float w = 0.004f * u;
-    const float r = sqrtf(1.0f + w) - 1.0f;
-    const float q = r / 0.002f;
-    const float y = q * q - 1.0f;
-    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-    return sgn * y;
-}
-
-// fp32 softmax over the children of one group (Node.expand, self_play.py:461-463): max, exp,
-// sum, multiply by the reciprocal -- torch's CPU kernel order -- widened to fp64 like .tolist().
-template <int G, int CH>
-__device__ __forceinline__ void group_softmax(const float (&logit)[CH], const bool (&valid)[CH], double (&prior)[CH]) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-        if (valid[c]) m = fmaxf(m, logit[c]);
-    m = group_maxf<G>(m);
-    float ex[CH];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        ex[c] = valid[c] ? expf(logit[c] - m) : 0.f;
-        s += ex[c];
+// per-search reset shared by the root kernels (MinMaxStats(), max_tree_depth; self_play.py:317-319)
+__device__ __forceinline__ void reset_search_state(const TreeParams& p, int e, const uint32_t* rng_skip) {
+    // advance the device RNG past the words the host mirror consumed (Dirichlet draw of this
+    // move, action sampling of the previous one)
+    const uint32_t skip = rng_skip ? rng_skip[e] : 0u;
+    if (skip) {
+        uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
+        int32_t pos = p.mt_pos[e];
+        for (uint32_t i = 0; i < skip; ++i) (void)mt_next(key, &pos);
+        p.mt_pos[e] = pos;
     }
-    s = group_sumf<G>(s);
-    const float inv = 1.0f / s;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) prior[c] = static_cast<double>(ex[c] * inv);
+    p.min_max[e] = MinMax{INFINITY, -INFINITY};
+    p.root_value_sum[e] = 0.0;
+    p.max_depth[e] = 0;
+    p.depth_sum[e] = 0;
+    p.tie_words[e] = 0u;
+    p.path_len[e] = 0;
+    p.leaf_parent[e] = 0;
 }
 
 // -------------------------------------------------------------------------------------------------
 // expand_roots: root.expand over the legal actions + exploration noise (self_play.py:293-315,
-// 452-477) and reset of the per-search state (MinMaxStats(), max_tree_depth; self_play.py:317-319).
+// 452-477) and reset of the per-search state.
 // -------------------------------------------------------------------------------------------------
 template <int G, int CH, bool INJECTED>
 __global__ __launch_bounds__(kThreads) void expand_roots_kernel(TreeParams p, const float* __restrict__ value_logits,
@@ -299,25 +188,7 @@ __global__ __launch_bounds__(kThreads) void expand_roots_kernel(TreeParams p, co
     const int j = threadIdx.x % G;
     if (e >= p.E) return;
     const int n_children = p.root_children[e];
-
-    if (j == 0) {
-        // advance the device RNG past the words the host mirror consumed (Dirichlet draw of this
-        // move, action sampling of the previous one)
-        uint32_t skip = rng_skip ? rng_skip[e] : 0u;
-        if (skip) {
-            uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
-            int32_t pos = p.mt_pos[e];
-            for (uint32_t i = 0; i < skip; ++i) (void)mt_next(key, &pos);
-            p.mt_pos[e] = pos;
-        }
-        p.min_max[e] = MinMax{INFINITY, -INFINITY};
-        p.root_value_sum[e] = 0.0;
-        p.max_depth[e] = 0;
-        p.depth_sum[e] = 0;
-        p.tie_words[e] = 0u;
-        p.path_len[e] = 0;
-        p.leaf_parent[e] = 0;
-    }
+    if (j == 0) reset_search_state(p, e, rng_skip);
     if (n_children == 0) return;
 
     double reward = 0.0;
@@ -352,25 +223,8 @@ __global__ __launch_bounds__(kThreads) void expand_roots_kernel(TreeParams p, co
         }
     }
     if (!INJECTED) group_softmax<G, CH>(logit, valid, prior);
-
-    uint8_t* blk = block_ptr(p, 0, e);
-    ChildStats* stats = reinterpret_cast<ChildStats*>(blk);
-    ChildLinks* links = reinterpret_cast<ChildLinks*>(blk + p.links_offset);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int child = c * G + j;
-        if (child < p.A) {
-            double pr = prior[c];
-            if (valid[c] && noise) {
-                // prior * (1 - frac) + n * frac   (self_play.py:477)
-                const double keep = pr * (1 - p.noise_frac);
-                const double add = noise[static_cast<size_t>(e) * p.A + child] * p.noise_frac;
-                pr = keep + add;
-            }
-            stats[child] = ChildStats{0.0, pr};
-            links[child] = ChildLinks{0.f, 0, -1, 0};
-        }
-    }
+    write_root_children<G, CH>(global_tree(p, e), p.A, n_children, prior,
+                               noise ? noise + static_cast<size_t>(e) * p.A : nullptr, p.noise_frac, j);
     if (root_hidden) {
         const float* src = root_hidden + static_cast<size_t>(e) * p.H;
         float* dst = p.hidden + static_cast<size_t>(e) * p.H;  // slab 0
@@ -381,18 +235,7 @@ __global__ __launch_bounds__(kThreads) void expand_roots_kernel(TreeParams p, co
 // -------------------------------------------------------------------------------------------------
 // expand_backup: decode value/reward, expand the leaf over the full action space, back the value
 // up the search path with min-max statistics (self_play.py:344-356, 407-431, 452-466, 560-562).
-//
-// The backup walks a path whose addresses are all known (written by select), so the group's lanes
-// first stage the (value_sum, visits, reward) triples of up to kStageLevels path nodes into LDS with
-// independent loads in flight, the group leader then runs the inherently sequential value
-// recursion out of LDS, and the lanes write the updated statistics back.
 // -------------------------------------------------------------------------------------------------
-struct StagedNode {
-    double value_sum;
-    float reward;
-    int32_t visits;
-};
-
 template <int G, int CH, bool INJECTED>
 __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, int sim,
                                                                  const float* __restrict__ value_logits,
@@ -410,9 +253,7 @@ __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, i
     if (e >= p.E) return;
     if (p.root_children[e] == 0) return;
     const int depth = p.path_len[e];  // >= 1
-    const int k_new = sim + 1;
 
-    // ---- decode the network heads -------------------------------------------------------------
     double value;
     float reward_f;
     if (INJECTED) {
@@ -441,114 +282,16 @@ __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, i
     }
     if (!INJECTED) group_softmax<G, CH>(logit, valid, prior);
 
-    // ---- expand: children of the new node (slab k_new is written contiguously over trees) ------
-    {
-        uint8_t* blk = block_ptr(p, k_new, e);
-        ChildStats* stats = reinterpret_cast<ChildStats*>(blk);
-        ChildLinks* links = reinterpret_cast<ChildLinks*>(blk + p.links_offset);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int child = c * G + j;
-            if (valid[c]) {
-                stats[child] = ChildStats{0.0, prior[c]};
-                links[child] = ChildLinks{0.f, 0, -1, 0};
-            }
-        }
-    }
+    const GlobalTree tree = global_tree(p, e);
+    write_children<G, CH>(tree, sim + 1, p.A, prior, j);  // slab sim+1 is contiguous over trees
 
-    // ---- backup ---------------------------------------------------------------------------------
-    const bool two_player = p.P == 2;
-    const double discount = p.discount;
     MinMax mm = p.min_max[e];
-    const double reward = static_cast<double>(reward_f);
-
-    // leaf (tree depth == depth): first visit, value_sum was 0; it is `to_play`'s own node
-    const int leaf_packed = p.path[static_cast<size_t>(depth - 1) * p.E + e];
+    double root_value_sum = (j == 0) ? p.root_value_sum[e] : 0.0;
+    const double root_reward = (j == 0) ? p.root_reward[e] : 0.0;
+    backup<G>(tree, depth, sim, value, reward_f, p.P == 2, p.discount, mm, root_value_sum, root_reward,
+              staged[tree_in_block], j);
     if (j == 0) {
-        uint8_t* blk = block_ptr(p, leaf_packed >> 16, e);
-        const int slot = leaf_packed & 0xffff;
-        ChildStats* st = reinterpret_cast<ChildStats*>(blk) + slot;
-        ChildLinks* lk = reinterpret_cast<ChildLinks*>(blk + p.links_offset) + slot;
-        const double vs = 0.0 + value;
-        st->value_sum = vs;
-        *lk = ChildLinks{reward_f, 1, k_new, 0};
-        const double q = vs / 1.0;
-        const double seen = two_player ? (reward + discount * -q) : (reward + discount * q);
-        mm.maximum = fmax(mm.maximum, seen);
-        mm.minimum = fmin(mm.minimum, seen);
-        value = (two_player ? -reward : reward) + discount * value;
-    }
-
-    // interior path nodes, leaf-side first, kStageLevels at a time
-    for (int hi = depth - 2; hi >= 0; hi -= kStageLevels) {
-        const int count = (hi + 1 < kStageLevels) ? hi + 1 : kStageLevels;  // levels hi, hi-1, ...
-        for (int i = j; i < count; i += G) {
-            const int packed = p.path[static_cast<size_t>(hi - i) * p.E + e];
-            const uint8_t* blk = block_ptr(p, packed >> 16, e);
-            const int slot = packed & 0xffff;
-            const ChildStats* st = reinterpret_cast<const ChildStats*>(blk) + slot;
-            const ChildLinks lk = *(reinterpret_cast<const ChildLinks*>(blk + p.links_offset) + slot);
-            staged[tree_in_block][i] = StagedNode{st->value_sum, lk.reward, lk.visits};
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (j == 0) {
-            for (int i = 0; i < count; ++i) {
-                StagedNode n = staged[tree_in_block][i];
-                const int level = hi - i;  // node's tree depth is level + 1
-                const double r = static_cast<double>(n.reward);
-                if (!two_player) {
-                    n.value_sum += value;
-                    n.visits += 1;
-                    const double q = n.value_sum / static_cast<double>(n.visits);
-                    const double seen = r + discount * q;
-                    mm.maximum = fmax(mm.maximum, seen);
-                    mm.minimum = fmin(mm.minimum, seen);
-                    value = r + discount * value;
-                } else {
-                    const bool same = ((depth - (level + 1)) & 1) == 0;  // node.to_play == to_play
-                    n.value_sum += same ? value : -value;
-                    n.visits += 1;
-                    const double q = n.value_sum / static_cast<double>(n.visits);
-                    const double seen = r + discount * -q;
-                    mm.maximum = fmax(mm.maximum, seen);
-                    mm.minimum = fmin(mm.minimum, seen);
-                    value = (same ? -r : r) + discount * value;
-                }
-                staged[tree_in_block][i] = n;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int i = j; i < count; i += G) {
-            const int packed = p.path[static_cast<size_t>(hi - i) * p.E + e];
-            uint8_t* blk = block_ptr(p, packed >> 16, e);
-            const int slot = packed & 0xffff;
-            const StagedNode n = staged[tree_in_block][i];
-            (reinterpret_cast<ChildStats*>(blk) + slot)->value_sum = n.value_sum;
-            (reinterpret_cast<ChildLinks*>(blk + p.links_offset) + slot)->visits = n.visits;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // root (tree depth 0), then per-search statistics
-    if (j == 0) {
-        double rvs = p.root_value_sum[e];
-        const double r = p.root_reward[e];
-        const double n_root = static_cast<double>(sim + 1);
-        double seen;
-        if (!two_player) {
-            rvs += value;
-            seen = r + discount * (rvs / n_root);
-        } else {
-            const bool same = (depth & 1) == 0;
-            rvs += same ? value : -value;
-            seen = r + discount * -(rvs / n_root);
-        }
-        mm.maximum = fmax(mm.maximum, seen);
-        mm.minimum = fmin(mm.minimum, seen);
-        p.root_value_sum[e] = rvs;
+        p.root_value_sum[e] = root_value_sum;
         p.min_max[e] = mm;
         if (depth > p.max_depth[e]) p.max_depth[e] = depth;
         p.depth_sum[e] += depth;
@@ -566,9 +309,201 @@ __global__ __launch_bounds__(256) void seed_streams_kernel(uint32_t* __restrict_
 }
 
 // -------------------------------------------------------------------------------------------------
+// Fully-connected network, lock-step form: the same device functions the fused kernel uses, one
+// launch per inference over the [E, .] batch (so the two shapes can be compared bit for bit).
+// -------------------------------------------------------------------------------------------------
+template <int G, bool INITIAL>
+__global__ __launch_bounds__(kThreads) void fc_inference_kernel(FcNet net, const float* __restrict__ weights, int E,
+                                                                const float* __restrict__ in,        // obs or hidden
+                                                                const int64_t* __restrict__ action,  // recurrent only
+                                                                float* __restrict__ value_logits,
+                                                                float* __restrict__ reward_logits,
+                                                                float* __restrict__ policy_logits,
+                                                                float* __restrict__ hidden_out) {
+    extern __shared__ __attribute__((aligned(16))) float fc_smem[];  // [padded weights][64/G][scratch_floats]
+    constexpr int kTrees = kThreads / G;
+    float* w_lds = fc_smem;
+    stage_fc_weights(net, weights, w_lds, threadIdx.x, kThreads);
+    __syncthreads();
+    const int tree_in_block = threadIdx.x / G;
+    const int e = blockIdx.x * kTrees + tree_in_block;
+    const int j = threadIdx.x % G;
+    if (e >= E) return;
+    float* scratch = fc_smem + ((net.n_weights_lds + 3) & ~3) + static_cast<size_t>(tree_in_block) * net.scratch_floats;
+    if (INITIAL) {
+        fc_initial<G>(net, w_lds, scratch, in + static_cast<size_t>(e) * net.obs, j);
+        for (int i = j; i < net.F; i += G)
+            reward_logits[static_cast<size_t>(e) * net.F + i] = (i == net.F / 2) ? 0.f : -INFINITY;
+    } else {
+        fc_recurrent<G>(net, w_lds, scratch, in + static_cast<size_t>(e) * net.enc, static_cast<int>(action[e]), j);
+        for (int i = j; i < net.F; i += G) reward_logits[static_cast<size_t>(e) * net.F + i] = scratch[net.off_reward + i];
+    }
+    for (int i = j; i < net.F; i += G) value_logits[static_cast<size_t>(e) * net.F + i] = scratch[net.off_value + i];
+    for (int i = j; i < net.A; i += G) policy_logits[static_cast<size_t>(e) * net.A + i] = scratch[net.off_policy + i];
+    for (int i = j; i < net.enc; i += G) hidden_out[static_cast<size_t>(e) * net.enc + i] = scratch[net.off_norm + i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Fused whole-move search for fully-connected networks (MCTS.run, self_play.py:261-362, for every
+// tree of the workgroup, in ONE launch).
+//
+// LDS per workgroup:  pb_c tables | network weights | per tree { child blocks (S+1) x stride,
+//                     path S x 4 B, activation scratch, optionally hidden states (S+1) x enc x 4 B }
+// Nothing is exchanged between trees, so there is no barrier after the initial staging.  Hidden
+// states are also streamed to the HBM pool (fire-and-forget) and, at the end, the child blocks are
+// copied out slab by slab, so readout / export see exactly what the lock-step kernels leave.
+// -------------------------------------------------------------------------------------------------
+template <int G, int CH>
+__global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p, FcNet net, FusedLayout lay,
+                                                                   const float* __restrict__ weights,
+                                                                   const float* __restrict__ observations,  // [E][obs]
+                                                                   const double* __restrict__ noise,        // [E][A] or null
+                                                                   const uint32_t* __restrict__ rng_skip, int n_sims) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    MZ_STAMP_DECL
+    double* pbc_table = reinterpret_cast<double*>(smem);
+    float* w_lds = reinterpret_cast<float*>(smem + lay.off_weights);
+    stage_pbc_table(pbc_table, p);
+    stage_fc_weights(net, weights, w_lds, threadIdx.x, kThreads);
+    __syncthreads();
+    MZ_STAMP(0);
+
+    constexpr int kTrees = kThreads / G;
+    const int tree_in_block = threadIdx.x / G;
+    const int e = blockIdx.x * kTrees + tree_in_block;
+    const int j = threadIdx.x % G;
+    const int group_base = threadIdx.x - j;
+    if (e >= p.E) return;
+    const int n_root = p.root_children[e];
+    if (j == 0) reset_search_state(p, e, rng_skip);
+    if (n_root == 0) return;
+
+    uint8_t* region = smem + lay.off_trees + static_cast<size_t>(tree_in_block) * lay.tree_bytes;
+    const LdsTree tree{region, p.block_stride, p.links_offset, reinterpret_cast<int32_t*>(region + lay.off_path)};
+    float* scratch = reinterpret_cast<float*>(region + lay.off_scratch);
+    const bool hidden_in_lds = lay.off_hidden != 0xffffffffu;
+    float* hidden_lds = hidden_in_lds ? reinterpret_cast<float*>(region + lay.off_hidden) : nullptr;
+    const int H = net.enc;
+    const bool two_player = p.P == 2;
+
+    // ---- root: initial inference, root.expand over the legal actions, exploration noise ----------
+    fc_initial<G>(net, w_lds, scratch, observations + static_cast<size_t>(e) * net.obs, j);
+    const float predicted = support_to_scalar_group<G>(scratch + net.off_value, net.F, net.support, j);
+    {
+        float logit[CH];
+        bool valid[CH];
+        double prior[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int child = c * G + j;
+            valid[c] = child < n_root;
+            prior[c] = 0.0;
+            logit[c] = valid[c] ? scratch[net.off_policy + p.root_action[static_cast<size_t>(e) * p.A + child]] : 0.f;
+        }
+        group_softmax<G, CH>(logit, valid, prior);
+        write_root_children<G, CH>(tree, p.A, n_root, prior, noise ? noise + static_cast<size_t>(e) * p.A : nullptr,
+                                   p.noise_frac, j);
+    }
+    for (int i = j; i < H; i += G) {
+        const float h = scratch[net.off_norm + i];
+        if (hidden_in_lds) hidden_lds[i] = h;
+        p.hidden[static_cast<size_t>(e) * H + i] = h;  // slab 0
+    }
+    group_memory_fence();
+
+    MinMax mm{INFINITY, -INFINITY};
+    double root_value_sum = 0.0;
+    const double root_reward = 0.0;  // log(one_hot(centre)) decodes to exactly 0
+    int32_t mt_pos = (j == 0) ? p.mt_pos[e] : 0;
+    uint32_t words = 0;
+    int max_depth = 0;
+    int64_t depth_sum = 0;
+    uint32_t* mt_key = p.mt_key + static_cast<size_t>(e) * kMtN;
+    MZ_STAMP(1);
+
+    // ---- S simulations, entirely inside the CU -----------------------------------------------------
+    for (int sim = 0; sim < n_sims; ++sim) {
+        const Descent d = descend<G, CH>(tree, pbc_table, p.S, p.A, sim, n_root, mm, p.discount, two_player, mt_key,
+                                         mt_pos, words, j, group_base, nullptr, 0, p.error_flag);
+        MZ_STAMP(2);
+        const int action = (d.depth == 1) ? p.root_action[static_cast<size_t>(e) * p.A + d.slot] : d.slot;
+        const float* parent_hidden = hidden_in_lds
+                                         ? hidden_lds + static_cast<size_t>(d.parent) * H
+                                         : p.hidden + (static_cast<size_t>(d.parent) * p.E + e) * H;
+        fc_recurrent<G>(net, w_lds, scratch, parent_hidden, action, j);
+        MZ_STAMP(3);
+        const double value = static_cast<double>(
+            support_to_scalar_group<G>(scratch + net.off_value, net.F, net.support, j));
+        const float reward_f = support_to_scalar_group<G>(scratch + net.off_reward, net.F, net.support, j);
+        float logit[CH];
+        bool valid[CH];
+        double prior[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int child = c * G + j;
+            valid[c] = child < p.A;
+            prior[c] = 0.0;
+            logit[c] = valid[c] ? scratch[net.off_policy + child] : 0.f;
+        }
+        group_softmax<G, CH>(logit, valid, prior);
+        MZ_STAMP(4);
+        const int k_new = sim + 1;
+        write_children<G, CH>(tree, k_new, p.A, prior, j);
+        for (int i = j; i < H; i += G) {
+            const float h = scratch[net.off_norm + i];
+            if (hidden_in_lds) hidden_lds[static_cast<size_t>(k_new) * H + i] = h;
+            p.hidden[(static_cast<size_t>(k_new) * p.E + e) * H + i] = h;
+        }
+        group_memory_fence();
+        MZ_STAMP(5);
+        backup<G>(tree, d.depth, sim, value, reward_f, two_player, p.discount, mm, root_value_sum, root_reward, nullptr, j);
+        group_memory_fence();
+        // the leader owns the running min-max statistics; every lane scores its child with them
+        mm.minimum = __shfl(mm.minimum, 0, G);
+        mm.maximum = __shfl(mm.maximum, 0, G);
+        if (d.depth > max_depth) max_depth = d.depth;
+        depth_sum += d.depth;
+        MZ_STAMP(6);
+    }
+
+    // ---- publish: per-tree statistics and the child blocks (what readout / export_tree read) -------
+    if (j == 0) {
+        p.root_reward[e] = root_reward;
+        p.root_predicted[e] = predicted;
+        p.root_value_sum[e] = root_value_sum;
+        p.min_max[e] = mm;
+        p.max_depth[e] = max_depth;
+        p.depth_sum[e] = depth_sum;
+        if (words) {
+            p.mt_pos[e] = mt_pos;
+            p.tie_words[e] = words;
+        }
+    }
+    const int block_words = static_cast<int>(p.block_stride / 16);
+    for (int k = 0; k <= n_sims; ++k) {
+        const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
+        uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.block_stride);
+        for (int i = j; i < block_words; i += G) dst[i] = src[i];
+    }
+    MZ_STAMP(7);
+    MZ_STAMP_FLUSH;
+}
+
+#ifdef MZ_STAMPS
+hipError_t read_stamp_sums(unsigned long long* out, bool reset) {
+    hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * 8);
+    if (err == hipSuccess && reset) {
+        unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        err = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sums), zeros, sizeof(zeros));
+    }
+    return err;
+}
+#endif
+
+// -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
-static int group_width(int A) {
+int default_group_width(int A) {
     int g = 1;
     while (g < A && g < 64) g <<= 1;
     return g;
@@ -577,14 +512,14 @@ static int group_width(int A) {
 template <int V>
 using IntC = std::integral_constant<int, V>;
 
-// Calls fn(IntC<G>{}, IntC<CH>{}) with the lane-group width / chunk count for A actions.
+// Calls fn(IntC<G>{}, IntC<CH>{}) for the tree's lane-group width / chunk count.
 template <typename Fn>
-static void dispatch_group(int A, Fn&& fn) {
-    if (A > 64) {
+static void dispatch_group(const TreeParams& p, Fn&& fn) {
+    if (p.A > 64) {
         fn(IntC<64>{}, IntC<kMaxChunks>{});
         return;
     }
-    switch (group_width(A)) {
+    switch (p.group) {
         case 1: fn(IntC<1>{}, IntC<1>{}); break;
         case 2: fn(IntC<2>{}, IntC<1>{}); break;
         case 4: fn(IntC<4>{}, IntC<1>{}); break;
@@ -596,8 +531,7 @@ static void dispatch_group(int A, Fn&& fn) {
 }
 
 static inline int tree_grid(const TreeParams& p) {
-    const int g = group_width(p.A);
-    const int trees = kThreads / g;
+    const int trees = kThreads / p.group;
     return (p.E + trees - 1) / trees;
 }
 
@@ -621,7 +555,7 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
     const size_t lds = sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1);
     const int grid = tree_grid(p);
     const bool fuse = p.H <= kFuseGatherMaxFloats;
-    dispatch_group(p.A, [&](auto g, auto ch) {
+    dispatch_group(p, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (fuse)
@@ -648,7 +582,7 @@ hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, c
                                const double* inj_priors, const double* noise, const uint32_t* rng_skip,
                                bool injected, hipStream_t stream, const LaunchTiming* timing) {
     const int grid = tree_grid(p);
-    dispatch_group(p.A, [&](auto g, auto ch) {
+    dispatch_group(p, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (injected)
@@ -666,7 +600,7 @@ hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value
                                 const double* inj_priors, bool injected, hipStream_t stream,
                                 const LaunchTiming* timing) {
     const int grid = tree_grid(p);
-    dispatch_group(p.A, [&](auto g, auto ch) {
+    dispatch_group(p, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
         if (injected)
@@ -689,6 +623,71 @@ hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t 
 
 hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream) {
     seed_streams_kernel<<<dim3((E + 255) / 256), dim3(256), 0, stream>>>(keys, pos, seeds, E);
+    return hipGetLastError();
+}
+
+hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const float* weights, bool initial, const float* in,
+                               const int64_t* action, float* value_logits, float* reward_logits, float* policy_logits,
+                               float* hidden_out, hipStream_t stream) {
+    const int grid = tree_grid(p);
+    dispatch_group(p, [&](auto g, auto) {
+        constexpr int G = decltype(g)::value;
+        const size_t lds = sizeof(float) * (static_cast<size_t>((net.n_weights_lds + 3) & ~3) +
+                                            static_cast<size_t>(net.scratch_floats) * (kThreads / G));
+        if (initial)
+            fc_inference_kernel<G, true><<<dim3(grid), dim3(kThreads), lds, stream>>>(
+                net, weights, p.E, in, action, value_logits, reward_logits, policy_logits, hidden_out);
+        else
+            fc_inference_kernel<G, false><<<dim3(grid), dim3(kThreads), lds, stream>>>(
+                net, weights, p.E, in, action, value_logits, reward_logits, policy_logits, hidden_out);
+    });
+    return hipGetLastError();
+}
+
+// LDS plan of the fused kernel for this (params, net, group); returns false if it cannot fit.
+bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_in_lds, size_t lds_limit,
+                       FusedLayout* out) {
+    FusedLayout lay{};
+    auto align16 = [](size_t v) { return (v + 15) / 16 * 16; };
+    size_t off = align16(sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1));
+    lay.off_weights = static_cast<uint32_t>(off);
+    off = align16(off + sizeof(float) * static_cast<size_t>(net.n_weights_lds));
+    lay.off_trees = static_cast<uint32_t>(off);
+    size_t t = static_cast<size_t>(p.S + 1) * p.block_stride;
+    lay.off_path = static_cast<uint32_t>(t);
+    t = align16(t + sizeof(int32_t) * static_cast<size_t>(p.S));
+    lay.off_scratch = static_cast<uint32_t>(t);
+    t = align16(t + sizeof(float) * static_cast<size_t>(net.scratch_floats));
+    const size_t trees = kThreads / p.group;
+    const size_t hidden_bytes = align16(sizeof(float) * static_cast<size_t>(p.S + 1) * net.enc);
+    if (want_hidden_in_lds && off + trees * (t + hidden_bytes) <= lds_limit) {
+        lay.off_hidden = static_cast<uint32_t>(t);
+        t += hidden_bytes;
+    } else {
+        lay.off_hidden = 0xffffffffu;
+    }
+    lay.tree_bytes = static_cast<uint32_t>(t);
+    lay.total_bytes = static_cast<uint32_t>(off + trees * t);
+    *out = lay;
+    return off + trees * t <= lds_limit;
+}
+
+hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
+                                  const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
+                                  hipStream_t stream, const LaunchTiming* timing) {
+    const int grid = tree_grid(p);
+    hipError_t attr_err = hipSuccess;
+    dispatch_group(p, [&](auto g, auto ch) {
+        constexpr int G = decltype(g)::value;
+        constexpr int CH = decltype(ch)::value;
+        auto kernel = search_fused_fc_kernel<G, CH>;
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lay.total_bytes));
+        if (attr_err != hipSuccess) return;
+        launch_kernel(kernel, dim3(grid), dim3(kThreads), lay.total_bytes, stream, timing, p, net, lay, weights,
+                      observations, noise, rng_skip, n_sims);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     return hipGetLastError();
 }
 

@@ -15,10 +15,20 @@
 #include <vector>
 
 #include "../../include/mzmcts.h"
+#include "fc_net_device.h"
 #include "np_legacy_rng.h"
 #include "tree_layout.h"
 
 namespace mz {
+int default_group_width(int A);
+hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const float* weights, bool initial, const float* in,
+                               const int64_t* action, float* value_logits, float* reward_logits, float* policy_logits,
+                               float* hidden_out, hipStream_t stream);
+bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_in_lds, size_t lds_limit,
+                       FusedLayout* out);
+hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
+                                  const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
+                                  hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
                          const LaunchTiming* timing);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -33,10 +43,17 @@ hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t 
 hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
 }  // namespace mz
 
+#ifdef MZ_STAMPS
+namespace mz {
+hipError_t read_stamp_sums(unsigned long long* out, bool reset);
+}
+#endif
+
 namespace {
 thread_local std::string g_create_error;
 
-enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfKinds = 3 };
+enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfFused = 3 };
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;  // gfx950
 struct EventPair {
     hipEvent_t begin, end;
     int kind;
@@ -83,6 +100,11 @@ struct mzmcts_engine {
     std::vector<int32_t> last_visits;       // [E][A] per slot
     std::vector<double> last_root_value_sum;
     std::vector<int32_t> last_root_visits;
+
+    // fully-connected network for the in-kernel inference paths
+    bool fc_ready = false;
+    mz::FcNet fc{};
+    const float* fc_weights = nullptr;
 
     // profiling
     bool profiling = false;
@@ -223,6 +245,15 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     p.F = 2 * c->support_size + 1;
     p.H = H;
     p.chunks = A > 64 ? (A + 63) / 64 : 1;
+    p.group = mz::default_group_width(A);
+    if (c->group_width != 0) {
+        const int g = c->group_width;
+        if (g < p.group || g > 64 || (g & (g - 1)) != 0) {
+            delete eng;
+            return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: group_width must be a power of two in [pow2(A), 64]");
+        }
+        p.group = g;
+    }
     p.links_offset = 16u * static_cast<uint32_t>(A);
     p.block_stride = mz::round_up(32u * static_cast<uint32_t>(A), 64u);
     p.discount = c->discount;
@@ -700,6 +731,134 @@ int mzmcts_export_tree(mzmcts_engine* eng, int32_t env, int32_t* visits, double*
     return MZMCTS_OK;
 }
 
+// ---- fully-connected network in-kernel ----------------------------------------------------------------
+static int bind_mlp(mz::FcMlp* m, int in, const int32_t* hidden, int n_hidden, int out, int* cursor, int* lds_cursor,
+                    int* max_hidden) {
+    if (n_hidden < 0 || n_hidden > mz::kFcMaxLayers - 1) return -1;
+    int widths[mz::kFcMaxLayers + 1];
+    widths[0] = in;
+    for (int i = 0; i < n_hidden; ++i) widths[i + 1] = hidden[i];
+    widths[n_hidden + 1] = out;
+    m->n_layers = n_hidden + 1;
+    for (int l = 0; l < m->n_layers; ++l) {
+        if (widths[l] <= 0 || widths[l + 1] <= 0 || widths[l] > mz::kFcMaxWidth || widths[l + 1] > mz::kFcMaxWidth) return -1;
+        m->layer[l].in = widths[l];
+        m->layer[l].out = widths[l + 1];
+        m->layer[l].w_off = *cursor;
+        *cursor += widths[l] * widths[l + 1];
+        m->layer[l].b_off = *cursor;
+        *cursor += widths[l + 1];
+        m->layer[l].in_pad = (widths[l] + 3) / 4 * 4;
+        m->layer[l].w_lds = *lds_cursor;
+        *lds_cursor += m->layer[l].in_pad * widths[l + 1];
+        m->layer[l].b_lds = *lds_cursor;
+        *lds_cursor += (widths[l + 1] + 3) / 4 * 4;
+        if (l < m->n_layers - 1 && widths[l + 1] > *max_hidden) *max_hidden = widths[l + 1];
+    }
+    return 0;
+}
+
+int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float* weights, int64_t n_weights) {
+    if (!eng || !d || !weights) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_configure: null argument");
+    if (d->encoding_size != eng->p.H)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_configure: encoding_size must equal the engine's hidden_floats");
+    mz::FcNet net{};
+    net.obs = d->observation_floats;
+    net.enc = d->encoding_size;
+    net.A = eng->p.A;
+    net.F = eng->p.F;
+    net.support = eng->p.support;
+    int cursor = 0, lds_cursor = 0, max_hidden = 1;
+    int rc = 0;
+    rc |= bind_mlp(&net.repr, net.obs, d->hidden[0], d->n_hidden[0], net.enc, &cursor, &lds_cursor, &max_hidden);
+    rc |= bind_mlp(&net.dyn, net.enc + net.A, d->hidden[1], d->n_hidden[1], net.enc, &cursor, &lds_cursor, &max_hidden);
+    rc |= bind_mlp(&net.reward, net.enc, d->hidden[2], d->n_hidden[2], net.F, &cursor, &lds_cursor, &max_hidden);
+    rc |= bind_mlp(&net.policy, net.enc, d->hidden[3], d->n_hidden[3], net.A, &cursor, &lds_cursor, &max_hidden);
+    rc |= bind_mlp(&net.value, net.enc, d->hidden[4], d->n_hidden[4], net.F, &cursor, &lds_cursor, &max_hidden);
+    if (rc != 0 || net.obs <= 0 || net.obs > mz::kFcMaxWidth)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_configure: layer sizes outside the supported range "
+                                             "(<= 3 hidden layers per MLP, widths <= 256)");
+    if (cursor != n_weights)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_configure: n_weights does not match the layer description");
+    net.n_weights = cursor;
+    net.n_weights_lds = lds_cursor;
+    auto pad4 = [](int v) { return (v + 3) / 4 * 4; };
+    int off = pad4(std::max(net.obs, net.enc + net.A));
+    net.off_t0 = off;
+    off += pad4(max_hidden);
+    net.off_t1 = off;
+    off += pad4(max_hidden);
+    net.off_raw = off;
+    off += pad4(net.enc);
+    net.off_norm = off;
+    off += pad4(net.enc);
+    net.off_reward = off;
+    off += pad4(net.F);
+    net.off_value = off;
+    off += pad4(net.F);
+    net.off_policy = off;
+    off += pad4(net.A);
+    net.scratch_floats = off;
+    eng->fc = net;
+    eng->fc_weights = weights;
+    eng->fc_ready = true;
+    return MZMCTS_OK;
+}
+
+int mzmcts_fc_initial_inference(mzmcts_engine* eng, const float* observations, float* value_logits, float* reward_logits,
+                                float* policy_logits, float* hidden_out, void* stream) {
+    if (!eng || !observations || !value_logits || !reward_logits || !policy_logits || !hidden_out)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: null argument");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: call mzmcts_fc_configure first");
+    MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, true, observations, nullptr, value_logits,
+                                        reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
+    return MZMCTS_OK;
+}
+
+int mzmcts_fc_recurrent_inference(mzmcts_engine* eng, const float* hidden, const int64_t* action, float* value_logits,
+                                  float* reward_logits, float* policy_logits, float* hidden_out, void* stream) {
+    if (!eng || !hidden || !action || !value_logits || !reward_logits || !policy_logits || !hidden_out)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: null argument");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: call mzmcts_fc_configure first");
+    MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, false, hidden, action, value_logits,
+                                        reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
+    return MZMCTS_OK;
+}
+
+int64_t mzmcts_fused_lds_bytes(mzmcts_engine* eng, int32_t hidden_in_lds) {
+    if (!eng || !eng->fc_ready) return 0;
+    mz::FusedLayout lay{};
+    if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay)) return 0;
+    return lay.total_bytes;
+}
+
+int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_t hidden_in_lds, void* stream_) {
+    if (!eng || !observations) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: null argument");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: call mzmcts_fc_configure first");
+    if (!eng->search_begun) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc called before begin_search");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    mz::FusedLayout lay{};
+    if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay))
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: the trees of one workgroup do not fit in 160 KB of LDS "
+                                             "(use a wider group_width or the lock-step path)");
+    {
+        ProfScope scope(eng, stream, kProfFused);
+        MZ_HIP(eng, mz::launch_search_fused_fc(eng->p, eng->fc, lay, eng->fc_weights, observations,
+                                               eng->noise_this_search ? eng->d_noise : nullptr, eng->d_skip, eng->p.S,
+                                               stream, scope.get()));
+    }
+    eng->roots_ready = true;
+    eng->sim = eng->p.S;
+    return MZMCTS_OK;
+}
+
+#ifdef MZ_STAMPS
+// diagnostic build only: per-phase cycle sums of the fused kernel (see tools/stamp_fused.py)
+int mzmcts_debug_read_stamps(unsigned long long* out, int32_t reset) {
+    return mz::read_stamp_sums(out, reset != 0) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int mzmcts_set_profiling(mzmcts_engine* eng, int32_t enabled) {
     if (!eng) return MZMCTS_ERR_INVALID;
     eng->profiling = enabled != 0;
@@ -721,6 +880,10 @@ int mzmcts_get_profile(mzmcts_engine* eng, mzmcts_profile* out, int32_t reset) {
             case kProfBackup:
                 eng->prof.expand_backup_ms += ms;
                 eng->prof.expand_backup_launches += 1;
+                break;
+            case kProfFused:
+                eng->prof.fused_ms += ms;
+                eng->prof.fused_launches += 1;
                 break;
             default:
                 eng->prof.root_ms += ms;

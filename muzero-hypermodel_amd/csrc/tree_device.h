@@ -1,0 +1,412 @@
+// tree_device.h -- device-side building blocks of the search, shared by the lock-step kernels
+// (tree in HBM, one kernel per phase) and the fused whole-move kernel (tree resident in LDS).
+//
+// Every function is written for a lane GROUP: the G = pow2 lanes of one wavefront that own a tree,
+// lane j handling child j (+ c*G for c < CH when the action space is wider than the group).  All
+// control flow inside these functions depends only on group-uniform values, so the intra-group
+// shuffles / ballots are convergent for the group even while other groups of the wave have left.
+//
+// `Acc` is the storage policy of one tree:
+//     ChildStats* stats(int k), ChildLinks* links(int k)      child block k of this tree
+//     void path_store(int level, int packed), int path_load(int level)
+//     static constexpr bool kInLds                             tree lives in LDS (fused kernel)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "np_legacy_rng.h"
+#include "tree_layout.h"
+
+namespace mz {
+
+constexpr int kStageLevels = 16;
+
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, G));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_maxf(float v) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, G));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_minf(float v) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, G));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sumf(float v) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) v = v + __shfl_xor(v, m, G);
+    return v;
+}
+
+// wave-level ordering point for values handed between lanes of a group through memory
+__device__ __forceinline__ void group_memory_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- storage policies ---------------------------------------------------------------------------
+struct GlobalTree {
+    static constexpr bool kInLds = false;
+    uint8_t* blocks;       // p.blocks + e * block_stride
+    size_t slab_stride;    // E * block_stride
+    uint32_t links_offset;
+    int32_t* path;         // p.path + e
+    int E;
+    __device__ __forceinline__ ChildStats* stats(int k) const {
+        return reinterpret_cast<ChildStats*>(blocks + static_cast<size_t>(k) * slab_stride);
+    }
+    __device__ __forceinline__ ChildLinks* links(int k) const {
+        return reinterpret_cast<ChildLinks*>(blocks + static_cast<size_t>(k) * slab_stride + links_offset);
+    }
+    __device__ __forceinline__ void path_store(int level, int packed) const {
+        path[static_cast<size_t>(level) * E] = packed;
+    }
+    __device__ __forceinline__ int path_load(int level) const { return path[static_cast<size_t>(level) * E]; }
+};
+
+__device__ __forceinline__ GlobalTree global_tree(const TreeParams& p, int e) {
+    return GlobalTree{p.blocks + static_cast<size_t>(e) * p.block_stride, static_cast<size_t>(p.E) * p.block_stride,
+                      p.links_offset, p.path + e, p.E};
+}
+
+struct LdsTree {
+    static constexpr bool kInLds = true;
+    uint8_t* blocks;       // this tree's (S+1) blocks, contiguous in LDS
+    uint32_t block_stride;
+    uint32_t links_offset;
+    int32_t* path;         // this tree's S path words in LDS
+    __device__ __forceinline__ ChildStats* stats(int k) const {
+        return reinterpret_cast<ChildStats*>(blocks + static_cast<uint32_t>(k) * block_stride);
+    }
+    __device__ __forceinline__ ChildLinks* links(int k) const {
+        return reinterpret_cast<ChildLinks*>(blocks + static_cast<uint32_t>(k) * block_stride + links_offset);
+    }
+    __device__ __forceinline__ void path_store(int level, int packed) const { path[level] = packed; }
+    __device__ __forceinline__ int path_load(int level) const { return path[level]; }
+};
+
+// ---- self_play.py:381-405 ucb_score, one child ----------------------------------------------------
+__device__ __forceinline__ double ucb_score(double pb_log, double pb_sqrt, const ChildStats& s,
+                                            const ChildLinks& l, double discount, bool two_player,
+                                            double mn, double mx) {
+    double pb_c = pb_log;
+    pb_c = pb_c * (pb_sqrt / static_cast<double>(l.visits + 1));
+    const double prior_score = pb_c * s.prior;
+    double value_score = 0.0;
+    if (l.visits > 0) {
+        double q = s.value_sum / static_cast<double>(l.visits);
+        if (two_player) q = -q;
+        const double v = static_cast<double>(l.reward) + discount * q;
+        value_score = (mx > mn) ? (v - mn) / (mx - mn) : v;
+    }
+    return prior_score + value_score;
+}
+
+struct Descent {
+    int depth;        // number of select steps == tree depth of the leaf
+    int parent;       // expanded-node index of the leaf's parent (its hidden-state slab)
+    int slot;         // child slot of the leaf inside its parent's block
+};
+
+// The `while node.expanded()` loop (self_play.py:321-335) with select_child (self_play.py:364-379).
+// pbc_table: [2][S+1] in LDS.  The group leader owns the RNG cursor (mt_pos / words).
+template <int G, int CH, typename Acc>
+__device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_table, int S, int A, int sim,
+                                           int n_root_children, const MinMax& mm, double discount, bool two_player,
+                                           uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j, int group_base,
+                                           int32_t* path_ties /* this tree's column or null */, int ties_stride,
+                                           int32_t* error_flag) {
+    int n_children = n_root_children;
+    int k = 0;    // expanded-node index of the current parent
+    int N = sim;  // its visit count: the root has been visited once per finished simulation
+    int depth = 0;
+    int slot = 0;
+    for (;;) {
+        const ChildStats* stats = acc.stats(k);
+        const ChildLinks* links = acc.links(k);
+        const double pb_log = pbc_table[N];
+        const double pb_sqrt = pbc_table[S + 1 + N];
+
+        double score[CH];
+        ChildLinks lk[CH];
+        double best = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int child = c * G + j;
+            score[c] = -INFINITY;
+            lk[c] = ChildLinks{0.f, 0, -1, 0};
+            if (child < n_children) {
+                const ChildStats st = stats[child];
+                lk[c] = links[child];
+                score[c] = ucb_score(pb_log, pb_sqrt, st, lk[c], discount, two_player, mm.minimum, mm.maximum);
+                best = fmax(best, score[c]);
+            }
+        }
+        best = group_max<G>(best);
+
+        // tie list in child order (self_play.py:372-378)
+        unsigned long long tie_mask[CH];
+        int n_ties = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const bool is_max = (c * G + j < n_children) && (score[c] == best);
+            const unsigned long long ballot = __ballot(is_max);
+            tie_mask[c] = (G == 64) ? ballot : ((ballot >> group_base) & ((1ull << G) - 1ull));
+            n_ties += __popcll(tie_mask[c]);
+        }
+        int pick = 0;
+        if (n_ties > 1) {
+            uint32_t r = 0;
+            if (j == 0) r = mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words);
+            pick = static_cast<int>(__shfl(r, 0, G));
+        } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
+            if (j == 0) atomicOr(error_flag, 1);
+            tie_mask[0] = 1ull;
+        }
+        int sel_visits = 0, sel_child = -1;
+        {
+            int remaining = pick;
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                unsigned long long m = tie_mask[c];
+                const int cnt = __popcll(m);
+                if (!found && remaining < cnt) {
+                    for (int i = 0; i < remaining; ++i) m &= m - 1ull;
+                    const int bit = __ffsll(static_cast<long long>(m)) - 1;
+                    slot = c * G + bit;
+                    sel_visits = __shfl(lk[c].visits, bit, G);
+                    sel_child = __shfl(lk[c].child_node, bit, G);
+                    found = true;
+                } else if (!found) {
+                    remaining -= cnt;  // (found / remaining are uniform across the group's lanes)
+                }
+            }
+        }
+        if (j == 0) {
+            acc.path_store(depth, (k << 16) | slot);
+            if (path_ties) path_ties[static_cast<size_t>(depth) * ties_stride] = n_ties;
+        }
+        ++depth;
+        if (sel_child < 0) break;  // reached a node that is not expanded yet
+        if (depth > sim) {         // cannot happen on a consistent tree (only sim+1 nodes are expanded);
+            if (j == 0) atomicOr(error_flag, 2);  // guarantees every wave leaves the loop regardless
+            break;
+        }
+        k = sel_child;
+        N = sel_visits;
+        n_children = A;
+    }
+    return Descent{depth, k, slot};
+}
+
+// models.py:641-662 support_to_scalar, fp32, torch's operation order; the F logits of one tree are
+// spread over the G lanes of its group.
+template <int G>
+__device__ __forceinline__ float support_to_scalar_group(const float* logits, int F, int support, int j) {
+    float m = -INFINITY;
+    for (int i = j; i < F; i += G) m = fmaxf(m, logits[i]);
+    m = group_maxf<G>(m);
+    float s = 0.f;
+    for (int i = j; i < F; i += G) s += expf(logits[i] - m);
+    s = group_sumf<G>(s);
+    const float inv = 1.0f / s;
+    float acc = 0.f;
+    for (int i = j; i < F; i += G) acc += static_cast<float>(i - support) * (expf(logits[i] - m) * inv);
+    const float x = group_sumf<G>(acc);
+    const float u = (fabsf(x) + 1.0f) + 0.001f;
+    const float w = 0.004f * u;
+    const float r = sqrtf(1.0f + w) - 1.0f;
+    const float q = r / 0.002f;
+    const float y = q * q - 1.0f;
+    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return sgn * y;
+}
+
+// fp32 softmax over the children of one group (Node.expand, self_play.py:461-463): max, exp,
+// sum, multiply by the reciprocal -- torch's CPU kernel order -- widened to fp64 like .tolist().
+template <int G, int CH>
+__device__ __forceinline__ void group_softmax(const float (&logit)[CH], const bool (&valid)[CH], double (&prior)[CH]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (valid[c]) m = fmaxf(m, logit[c]);
+    m = group_maxf<G>(m);
+    float ex[CH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        ex[c] = valid[c] ? expf(logit[c] - m) : 0.f;
+        s += ex[c];
+    }
+    s = group_sumf<G>(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) prior[c] = static_cast<double>(ex[c] * inv);
+}
+
+// node.expand over the full action space (self_play.py:346-352, 452-466): children of node k_new.
+template <int G, int CH, typename Acc>
+__device__ __forceinline__ void write_children(const Acc& acc, int k_new, int A, const double (&prior)[CH], int j) {
+    ChildStats* stats = acc.stats(k_new);
+    ChildLinks* links = acc.links(k_new);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int child = c * G + j;
+        if (child < A) {
+            stats[child] = ChildStats{0.0, prior[c]};
+            links[child] = ChildLinks{0.f, 0, -1, 0};
+        }
+    }
+}
+
+struct StagedNode {
+    double value_sum;
+    float reward;
+    int32_t visits;
+};
+
+// one interior node of the search path (self_play.py:412-428); `same` = node.to_play == to_play
+__device__ __forceinline__ void backup_step(double& value_sum, int32_t& visits, double r, bool two_player, bool same,
+                                            double discount, double& value, MinMax& mm) {
+    if (!two_player) {
+        value_sum += value;
+        visits += 1;
+        const double q = value_sum / static_cast<double>(visits);
+        const double seen = r + discount * q;
+        mm.maximum = fmax(mm.maximum, seen);
+        mm.minimum = fmin(mm.minimum, seen);
+        value = r + discount * value;
+    } else {
+        value_sum += same ? value : -value;
+        visits += 1;
+        const double q = value_sum / static_cast<double>(visits);
+        const double seen = r + discount * -q;
+        mm.maximum = fmax(mm.maximum, seen);
+        mm.minimum = fmin(mm.minimum, seen);
+        value = (same ? -r : r) + discount * value;
+    }
+}
+
+// backpropagate (self_play.py:407-431) along the path recorded by descend(), leaf first; the leaf's
+// own record (reward, first visit, link to its new children) is written here too.  mm and
+// root_value_sum are the group leader's registers.  `staged`: kStageLevels LDS slots of this tree
+// (only used when the tree itself is in HBM: the lanes fetch the path's records with independent
+// loads in flight, the leader runs the sequential recursion out of LDS, the lanes write back).
+template <int G, typename Acc>
+__device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, double value, float reward_f, bool two_player,
+                                       double discount, MinMax& mm, double& root_value_sum, double root_reward,
+                                       StagedNode* staged, int j) {
+    const int k_new = sim + 1;
+    const double reward = static_cast<double>(reward_f);
+    // leaf (tree depth == depth): first visit, value_sum was 0; it is `to_play`'s own node
+    if (j == 0) {
+        const int packed = acc.path_load(depth - 1);
+        const int slot = packed & 0xffff;
+        ChildStats* st = acc.stats(packed >> 16) + slot;
+        ChildLinks* lk = acc.links(packed >> 16) + slot;
+        const double vs = 0.0 + value;
+        st->value_sum = vs;
+        *lk = ChildLinks{reward_f, 1, k_new, 0};
+        const double q = vs / 1.0;
+        const double seen = two_player ? (reward + discount * -q) : (reward + discount * q);
+        mm.maximum = fmax(mm.maximum, seen);
+        mm.minimum = fmin(mm.minimum, seen);
+        value = (two_player ? -reward : reward) + discount * value;
+    }
+    if constexpr (Acc::kInLds) {
+        if (j == 0) {
+            for (int level = depth - 2; level >= 0; --level) {
+                const int packed = acc.path_load(level);
+                const int slot = packed & 0xffff;
+                ChildStats* st = acc.stats(packed >> 16) + slot;
+                ChildLinks* lk = acc.links(packed >> 16) + slot;
+                double vs = st->value_sum;
+                int32_t visits = lk->visits;
+                const bool same = ((depth - (level + 1)) & 1) == 0;
+                backup_step(vs, visits, static_cast<double>(lk->reward), two_player, same, discount, value, mm);
+                st->value_sum = vs;
+                lk->visits = visits;
+            }
+        }
+    } else {
+        for (int hi = depth - 2; hi >= 0; hi -= kStageLevels) {
+            const int count = (hi + 1 < kStageLevels) ? hi + 1 : kStageLevels;  // levels hi, hi-1, ...
+            for (int i = j; i < count; i += G) {
+                const int packed = acc.path_load(hi - i);
+                const int slot = packed & 0xffff;
+                const ChildStats* st = acc.stats(packed >> 16) + slot;
+                const ChildLinks lk = *(acc.links(packed >> 16) + slot);
+                staged[i] = StagedNode{st->value_sum, lk.reward, lk.visits};
+            }
+            group_memory_fence();
+            if (j == 0) {
+                for (int i = 0; i < count; ++i) {
+                    StagedNode n = staged[i];
+                    const int level = hi - i;  // node's tree depth is level + 1
+                    const bool same = ((depth - (level + 1)) & 1) == 0;
+                    backup_step(n.value_sum, n.visits, static_cast<double>(n.reward), two_player, same, discount, value,
+                                mm);
+                    staged[i] = n;
+                }
+            }
+            group_memory_fence();
+            for (int i = j; i < count; i += G) {
+                const int packed = acc.path_load(hi - i);
+                const int slot = packed & 0xffff;
+                const StagedNode n = staged[i];
+                (acc.stats(packed >> 16) + slot)->value_sum = n.value_sum;
+                (acc.links(packed >> 16) + slot)->visits = n.visits;
+            }
+            group_memory_fence();
+        }
+    }
+    // root (tree depth 0)
+    if (j == 0) {
+        const double n_root = static_cast<double>(sim + 1);
+        double seen;
+        if (!two_player) {
+            root_value_sum += value;
+            seen = root_reward + discount * (root_value_sum / n_root);
+        } else {
+            const bool same = (depth & 1) == 0;
+            root_value_sum += same ? value : -value;
+            seen = root_reward + discount * -(root_value_sum / n_root);
+        }
+        mm.maximum = fmax(mm.maximum, seen);
+        mm.minimum = fmin(mm.minimum, seen);
+    }
+}
+
+// root.expand over the legal actions + add_exploration_noise (self_play.py:303-315, 452-477).
+// prior[c] arrives soft-maxed (or injected) for child slot c*G+j; noise_row may be null.
+template <int G, int CH, typename Acc>
+__device__ __forceinline__ void write_root_children(const Acc& acc, int A, int n_children, double (&prior)[CH],
+                                                    const double* noise_row, double noise_frac, int j) {
+    ChildStats* stats = acc.stats(0);
+    ChildLinks* links = acc.links(0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int child = c * G + j;
+        if (child < A) {
+            double pr = (child < n_children) ? prior[c] : 0.0;
+            if (child < n_children && noise_row) {
+                // prior * (1 - frac) + n * frac   (self_play.py:477)
+                const double keep = pr * (1 - noise_frac);
+                const double add = noise_row[child] * noise_frac;
+                pr = keep + add;
+            }
+            stats[child] = ChildStats{0.0, pr};
+            links[child] = ChildLinks{0.f, 0, -1, 0};
+        }
+    }
+}
+
+}  // namespace mz

@@ -45,6 +45,7 @@ struct alignas(16) MinMax {
 struct TreeParams {
     int32_t E, A, S, P, F, support, H;
     int32_t chunks;          // ceil(A / 64) when A > 64, else 1
+    int32_t group;           // lanes per tree: pow2 >= min(A, 64), one wavefront holds 64/group trees
     uint32_t block_stride;   // bytes per child block
     uint32_t links_offset;   // 16 * A
     double discount;

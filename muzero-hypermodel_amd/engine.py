@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _native
-from ._native import MzConfig, MzProfile, MzRootStats, c_f64_p, c_i32_p, c_i64_p, c_u32_p, ptr
+from ._native import MzConfig, MzFcDesc, MzProfile, MzRootStats, c_f64_p, c_i32_p, c_i64_p, c_u32_p, ptr
 
 
 def hidden_state_shape(config):
@@ -39,7 +39,7 @@ def hidden_state_shape(config):
 
 
 class BatchedMCTS:
-    def __init__(self, config, num_envs, device=None, seeds=None, use_graph=False):
+    def __init__(self, config, num_envs, device=None, seeds=None, use_graph=False, group_width=0):
         if len(config.players) > 2:
             raise NotImplementedError("More than two player mode not implemented.")
         if list(config.players) != list(range(len(config.players))):
@@ -64,6 +64,10 @@ class BatchedMCTS:
         self._eager_searches = 0
         self._graph_model = None
         self._profiling = False
+        self._group_width = int(group_width)
+        self._fc_model = None
+        self._fc_flat = None
+        self.fused_hidden_in_lds = True
 
         with torch.cuda.device(self.device):
             self.pool = torch.empty((self.S + 1, self.E, self.H), dtype=torch.float32, device=self.device)
@@ -71,7 +75,7 @@ class BatchedMCTS:
             self.batch_action = torch.zeros((self.E, 1), dtype=torch.int64, device=self.device)
         cfg = MzConfig(num_envs=self.E, num_actions=self.A, num_simulations=self.S,
                        num_players=len(config.players), support_size=int(config.support_size),
-                       hidden_floats=self.H, device=self.device.index, reserved=0,
+                       hidden_floats=self.H, device=self.device.index, group_width=int(group_width),
                        discount=float(config.discount), pb_c_base=float(config.pb_c_base),
                        pb_c_init=float(config.pb_c_init),
                        root_dirichlet_alpha=float(config.root_dirichlet_alpha),
@@ -145,16 +149,21 @@ class BatchedMCTS:
         return ("MT19937", key, pos.value, hg.value, g.value)
 
     # ---- low-level steps (also what the parity tests drive) -------------------------------------
-    def begin_search(self, legal_actions, to_play, add_exploration_noise=True):
-        """legal_actions: per env a sequence of actions (empty / None = env inactive this search)."""
-        self._legal[:] = 0
-        for e, legal in enumerate(legal_actions):
-            n = 0 if legal is None else len(legal)
-            if n > self.A:
-                raise AssertionError("Legal actions should be a subset of the action space.")
-            self._nlegal[e] = n
-            if n:
-                self._legal[e, :n] = legal
+    def begin_search(self, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
+        """legal_actions: per env a sequence of actions (empty / None = env inactive this search), or --
+        the loop-free form for large E -- an int32 array [E, A] whose row e holds num_legal[e] actions."""
+        if num_legal is not None:
+            self._legal[:] = legal_actions
+            self._nlegal[:] = num_legal
+        else:
+            self._legal[:] = 0
+            for e, legal in enumerate(legal_actions):
+                n = 0 if legal is None else len(legal)
+                if n > self.A:
+                    raise AssertionError("Legal actions should be a subset of the action space.")
+                self._nlegal[e] = n
+                if n:
+                    self._legal[e, :n] = legal
         self._to_play[:] = np.asarray(to_play, dtype=np.int32)
         self._check(self._lib.mzmcts_begin_search(
             self._h, ptr(self._legal, c_i32_p), ptr(self._nlegal, c_i32_p), ptr(self._to_play, c_i32_p),
@@ -264,14 +273,105 @@ class BatchedMCTS:
             self._simulate_once(model)
         self._eager_searches += 1
 
+    # ---- fully-connected networks in-kernel ---------------------------------------------------------
+    def configure_fused_fc(self, model, flat=None):
+        """Hand a MuZeroFullyConnectedNetwork to the HIP library: afterwards `search(model, ...)` runs the
+        whole move in one launch (trees, hidden states, activations and weights resident in LDS).
+        `flat`: the weights.FlatWeights of `model` (created if omitted); its buffer is what the kernel
+        reads, so an RCCL weight broadcast into it refreshes the in-kernel network as well."""
+        from .weights import FlatWeights
+        cfg = self.config
+        if cfg.network != "fullyconnected":
+            raise NotImplementedError("the fused search covers fully-connected networks; residual networks "
+                                      "use the lock-step path with PyTorch-ROCm inference")
+        flat = flat if flat is not None else FlatWeights(model)
+        c, h, w = cfg.observation_shape
+        desc = MzFcDesc()
+        desc.observation_floats = c * h * w * (cfg.stacked_observations + 1) + cfg.stacked_observations * h * w
+        desc.encoding_size = cfg.encoding_size
+        for i, layers in enumerate((cfg.fc_representation_layers, cfg.fc_dynamics_layers, cfg.fc_reward_layers,
+                                    cfg.fc_policy_layers, cfg.fc_value_layers)):
+            if len(layers) > 3:
+                raise NotImplementedError("fused FC search supports at most 3 hidden layers per MLP")
+            desc.n_hidden[i] = len(layers)
+            for k, width in enumerate(layers):
+                desc.hidden[i][k] = int(width)
+        self._check(self._lib.mzmcts_fc_configure(self._h, ctypes.byref(desc), flat.flat.data_ptr(), flat.numel))
+        self._fc_model, self._fc_flat = model, flat
+        self._fc_out = (torch.empty((self.E, self.F), dtype=torch.float32, device=self.device),
+                        torch.empty((self.E, self.F), dtype=torch.float32, device=self.device),
+                        torch.empty((self.E, self.A), dtype=torch.float32, device=self.device))
+        return flat
+
+    def group_width(self):
+        """Lanes of a wavefront that own one tree."""
+        g = self._group_width
+        if g:
+            return g
+        g = 1
+        while g < self.A and g < 64:
+            g <<= 1
+        return g
+
+    def fused_lds_bytes(self, hidden_in_lds=True):
+        return int(self._lib.mzmcts_fused_lds_bytes(self._h, 1 if hidden_in_lds else 0))
+
+    def fc_initial_inference(self, observations):
+        """initial_inference by the library's own FC kernels: (value, reward, policy logits, hidden)."""
+        obs = observations.to(self.device, dtype=torch.float32).reshape(self.E, -1).contiguous()
+        v, r, p = self._fc_out
+        hidden = torch.empty((self.E, self.H), dtype=torch.float32, device=self.device)
+        self._check(self._lib.mzmcts_fc_initial_inference(self._h, obs.data_ptr(), v.data_ptr(), r.data_ptr(),
+                                                          p.data_ptr(), hidden.data_ptr(), self._stream()))
+        return v, r, p, hidden
+
+    def fc_recurrent_inference(self, hidden, action, out_state=None):
+        hidden = hidden.reshape(self.E, self.H).contiguous()
+        action = action.reshape(self.E).contiguous()
+        out = out_state if out_state is not None else torch.empty((self.E, self.H), dtype=torch.float32,
+                                                                  device=self.device)
+        v, r, p = self._fc_out
+        self._check(self._lib.mzmcts_fc_recurrent_inference(self._h, hidden.data_ptr(), action.data_ptr(),
+                                                            v.data_ptr(), r.data_ptr(), p.data_ptr(),
+                                                            out.data_ptr(), self._stream()))
+        return v, r, p, out
+
+    def search_lockstep_fc(self, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
+        """The lock-step pipeline with the library's FC kernels as the inference engine (no PyTorch modules):
+        the reference shape the fused kernel is checked against bit for bit."""
+        obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
+        with torch.cuda.device(self.device):
+            v, r, p, hidden = self.fc_initial_inference(obs)
+            self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
+            self.expand_roots(v, None, p, hidden)
+            for _ in range(self.S):
+                self.select()
+                v, r, p, _ = self.fc_recurrent_inference(self.batch_hidden, self.batch_action,
+                                                         out_state=self.pool[self._lib.mzmcts_next_slab(self._h)])
+                self.expand_backup(v, r, p, None)
+            return self.readout()
+
+    def search_fused(self, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
+        """MCTS.run for all envs in ONE kernel launch (after configure_fused_fc)."""
+        obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
+        obs = obs.to(self.device, dtype=torch.float32).reshape(self.E, -1).contiguous()
+        with torch.cuda.device(self.device):
+            self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
+            self._keep = (obs,)
+            self._check(self._lib.mzmcts_search_fused_fc(self._h, obs.data_ptr(),
+                                                         1 if self.fused_hidden_in_lds else 0, self._stream()))
+            return self.readout()
+
     @torch.no_grad()
-    def search(self, model, observations, legal_actions, to_play, add_exploration_noise=True):
+    def search(self, model, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
         """MCTS.run for all envs.  observations: [E, C, H, W] (numpy or tensor)."""
+        if self._fc_model is not None and model is self._fc_model:
+            return self.search_fused(observations, legal_actions, to_play, add_exploration_noise, num_legal)
         obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
         obs = obs.to(self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             value, reward, policy, hidden = model.initial_inference(obs)
-            self.begin_search(legal_actions, to_play, add_exploration_noise)
+            self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
             self.expand_roots(value, reward.contiguous(), policy, hidden)
             self._run_simulations(model)
             return self.readout()

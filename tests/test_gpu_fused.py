@@ -1,0 +1,164 @@
+"""The fully-connected network as HIP device code and the fused whole-move kernel (LDS-resident trees).
+
+  fc kernels vs torch      the library's FC inference vs the PyTorch modules and the reference's recorded
+                           outputs (fixture G2): logits / states within 1e-5
+  fused vs lock-step       search_fused_fc_kernel vs select -> fc kernel -> expand_backup with the same lane
+                           group width: the SAME device functions on a tree in LDS vs a tree in HBM, so every
+                           integer and fp64 statistic and every hidden state must be BIT-IDENTICAL
+  fused vs reference       golden CartPole traces: identical paths, value targets within 3e-5, policy targets
+                           and sampled actions identical
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from parity_helpers import cartpole_model_and_weights, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    assert torch.cuda.is_available()
+    return importlib.import_module("muzero-hypermodel_amd.engine")
+
+
+@pytest.fixture(scope="module")
+def models_mod(pkg):
+    return importlib.import_module("muzero-hypermodel_amd.models")
+
+
+def cartpole_config():
+    return importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
+
+
+def copy_stats(st):
+    return {k: v.copy() for k, v in st.items()}
+
+
+def test_fc_kernels_match_torch_and_reference(eng, models_mod):
+    config = cartpole_config()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g2_fc_inference")
+    E = len(fx["obs"])
+    for group in (0, 4, 16):
+        engine = eng.BatchedMCTS(config, E, group_width=group)
+        engine.configure_fused_fc(model)
+        v, r, p, h = engine.fc_initial_inference(torch.from_numpy(fx["obs"]).cuda())
+        for got, key in ((v, "init_value"), (p, "init_policy"), (h, "init_hidden")):
+            np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=1e-5, atol=1e-5, err_msg=key)
+        assert np.array_equal(r.cpu().numpy(), fx["init_reward"])
+        hidden = torch.from_numpy(fx["init_hidden"]).cuda()
+        action = torch.from_numpy(fx["actions"]).cuda()
+        v, r, p, h = engine.fc_recurrent_inference(hidden, action)
+        with torch.no_grad():
+            tv, tr, tp, th = model.recurrent_inference(hidden, action)
+        for got, ref, key in ((v, tv, "rec_value"), (r, tr, "rec_reward"), (p, tp, "rec_policy"), (h, th, "rec_hidden")):
+            np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=1e-5, atol=1e-5, err_msg=key)
+            np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5, err_msg=key)
+        engine.close()
+
+
+@pytest.mark.parametrize("group,hidden_in_lds", [(0, True), (0, False), (4, True), (8, True), (16, False)])
+def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds):
+    config = cartpole_config()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g4_cartpole_traces")
+    T = len(fx["seed"])
+    reps = 5                                    # 160 trees: several workgroups, a ragged last one
+    E = T * reps - 3
+    seeds = ([int(s) for s in fx["seed"]] * reps)[:E]
+    obs = np.concatenate([fx["obs"]] * reps)[:E]
+    legal, to_play = [[0, 1]] * E, [0] * E
+    results = []
+    for fused in (False, True):
+        engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=group)
+        engine.configure_fused_fc(model)
+        engine.fused_hidden_in_lds = hidden_in_lds
+        if fused:
+            assert engine.fused_lds_bytes(hidden_in_lds) > 0
+        moves = []
+        for move in range(2):                   # second move: RNG mirrors must still be in step
+            run = engine.search_fused if fused else engine.search_lockstep_fc
+            st = copy_stats(run(torch.from_numpy(obs), legal, to_play, True))
+            actions, _ = engine.sample_actions(1.0)
+            tree = engine.export_tree(E - 1)
+            moves.append((st, actions.copy(), tree, engine.pool.clone().cpu().numpy(), engine.noise.copy()))
+        engine.close()
+        results.append(moves)
+    for (a_st, a_act, a_tree, a_pool, a_noise), (b_st, b_act, b_tree, b_pool, b_noise) in zip(*results):
+        for key in a_st:
+            assert np.array_equal(a_st[key], b_st[key]), key
+        assert np.array_equal(a_act, b_act) and np.array_equal(a_noise, b_noise)
+        for key in a_tree:
+            assert np.array_equal(a_tree[key], b_tree[key]), f"tree {key}"
+        assert np.array_equal(a_pool, b_pool)   # every hidden state of every tree
+
+
+def test_fused_vs_reference_traces(eng, models_mod):
+    config = cartpole_config()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g4_cartpole_traces")
+    T = len(fx["seed"])
+    engine = eng.BatchedMCTS(config, T, seeds=[int(s) for s in fx["seed"]], group_width=4)
+    engine.configure_fused_fc(model)
+    st = engine.search(model, fx["obs"], [[0, 1]] * T, [0] * T, True)      # dispatches to the fused kernel
+    cv, rv = engine.search_statistics()
+    actions, _ = engine.sample_actions(fx["temperature"].tolist())
+    engine.close()
+    assert np.array_equal(engine.noise, fx["noise"])
+    agree = 0
+    for t in range(T):
+        assert st["visits"][t].sum() == config.num_simulations
+        assert abs(st["root_predicted_value"][t] - fx["root_predicted_value"][t]) <= 3e-5 * abs(fx["root_predicted_value"][t])
+        if not np.array_equal(st["visits"][t], fx["visits"][t]) or st["depth_sum"][t] != fx["sim_depth"][t].sum():
+            continue
+        agree += 1
+        assert np.array_equal(cv[t], fx["child_visits_target"][t])
+        assert abs(rv[t] - fx["root_value_target"][t]) <= 3e-5 * abs(fx["root_value_target"][t])
+        assert st["max_tree_depth"][t] == fx["max_tree_depth"][t]
+        assert actions[t] == fx["action_T"][t]
+    print(f"fused vs reference: {agree}/{T} traces with identical visit counts and depth sums")
+    assert agree >= 0.8 * T
+
+
+def test_fused_full_size_invariants_and_determinism(eng, models_mod):
+    config = cartpole_config()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    E, S = 4096, config.num_simulations
+    obs = torch.from_numpy(np.random.RandomState(123).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).cuda()
+    legal = np.tile(np.array([0, 1], dtype=np.int32), (E, 1))
+    runs = []
+    for _ in range(2):
+        engine = eng.BatchedMCTS(config, E, group_width=4)
+        engine.configure_fused_fc(model)
+        st = copy_stats(engine.search_fused(obs, legal, [0] * E, True, num_legal=np.full(E, 2, np.int32)))
+        runs.append(st)
+        engine.close()
+    st = runs[0]
+    assert (st["visits"].sum(axis=1) == S).all() and (st["root_visits"] == S).all()
+    assert (st["max_tree_depth"] >= 1).all() and (st["depth_sum"] >= S).all()
+    np.testing.assert_allclose(st["child_prior"].sum(axis=1), 1.0, rtol=0, atol=1e-6)
+    for key in st:
+        assert np.array_equal(st[key], runs[1][key]), key
+
+
+def test_fused_inactive_envs_and_weight_refresh(eng, models_mod):
+    config = cartpole_config()
+    model, weights = cartpole_model_and_weights(models_mod, config, "cuda")
+    E = 48
+    obs = torch.from_numpy(np.random.RandomState(1).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).cuda()
+    legal = [[0, 1] if e % 5 else [] for e in range(E)]
+    engine = eng.BatchedMCTS(config, E, group_width=4)
+    flat = engine.configure_fused_fc(model)
+    st1 = copy_stats(engine.search_fused(obs, legal, [0] * E, True))
+    for e in range(E):
+        assert st1["visits"][e].sum() == (config.num_simulations if e % 5 else 0)
+    # a weight refresh into the flat buffer (what an RCCL broadcast does) changes the in-kernel network
+    flat.flat.mul_(0.5)
+    st2 = copy_stats(engine.search_fused(obs, legal, [0] * E, True))
+    assert not np.array_equal(st1["root_predicted_value"], st2["root_predicted_value"])
+    engine.close()
