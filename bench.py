@@ -61,13 +61,15 @@ def parse_args():
                          "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
+    ap.add_argument("--groups", type=int, default=4,
+                    help="fused mode: env groups per GPU searched concurrently on separate HIP streams")
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
     from parity_helpers import load_golden
-    actor_mod, cartpole = pkg("actor"), pkg("games.cartpole")
+    actor_mod, cartpole, engine_mod = pkg("actor"), pkg("games.cartpole"), pkg("engine")
     rank, world, local_rank = actor_mod.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
@@ -99,6 +101,36 @@ def main():
         engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
         engine.sample_actions(temperature)
 
+    single_engine_step = one_step
+    pipe = None
+    if fused and args.groups > 1:
+        # n env groups on n streams: one group's host work overlaps the other groups' kernels
+        n = args.groups
+        pipe = engine_mod.PipelinedSearch(config, E, model, actor.flat, groups=n, device=device,
+                                          seeds=actor_mod.shard_seeds(config.seed, rank, E), group_width=group)
+        per = E // n
+        g_obs = [[o.reshape(E, -1)[pipe.slice(g)].contiguous() for g in range(n)] for o in obs_sets]
+        g_legal, g_nl, g_tp, g_temp = legal[:per], num_legal[:per], to_play[:per], temperature[:per]
+        started = [False] * n
+
+        def one_step(i):  # noqa: F811 -- one move for every group, pipelined across groups and steps
+            if world > 1 and args.bcast_every and i % args.bcast_every == 0:
+                torch.cuda.synchronize(device)          # weights are shared by all groups' kernels
+                actor.refresh_weights(src=0)
+            for g in range(n):
+                if started[g]:
+                    pipe.finish(g)
+                    pipe.engines[g].sample_actions(g_temp)
+                pipe.begin(g, g_obs[i % len(obs_sets)][g], g_legal, g_tp, True, num_legal=g_nl)
+                started[g] = True
+
+        def drain():
+            for g in range(n):
+                if started[g]:
+                    pipe.finish(g)
+                    pipe.engines[g].sample_actions(g_temp)
+                    started[g] = False
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -106,10 +138,14 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    if pipe:
+        drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    if pipe:
+        drain()                                          # every queued move is finished inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -129,6 +165,7 @@ def main():
                    "network": "fullyconnected (reference checkpoint), fp32 inference "
                               + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm"),
                    "mode": args.mode, "lanes_per_tree": engine.group_width(),
+                   "env_groups_per_gpu": args.groups if (fused and args.groups > 1) else 1,
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
                    "parallelism": f"actors{world}",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
@@ -137,7 +174,7 @@ def main():
 
     if rank == 0:
         if args.profile_steps > 0:
-            result["roofline"], result["kernels"] = roofline_leg(engine, one_step, args.profile_steps, device)
+            result["roofline"], result["kernels"] = roofline_leg(engine, single_engine_step, args.profile_steps, device)
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline_leg(config, w, args.cpu_seconds)
             result["speedup_vs_reference_equivalent"] = value / result["cpu_baseline"]["reference_equivalent_value"]

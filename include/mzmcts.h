@@ -167,6 +167,10 @@ int mzmcts_set_simulations_done(mzmcts_engine *engine, int32_t n);
  * readout: copy the root statistics of all trees to the host (blocking) and advance the host RNG
  * mirrors by the tie-break words each tree consumed. */
 int mzmcts_readout(mzmcts_engine *engine, const mzmcts_root_stats *out, void *stream);
+/* Asynchronous form: queue the device->host copies behind the search on `stream` and return at once;
+ * the next mzmcts_readout() then only waits for them.  Lets a host that drives several engines (env
+ * groups) overlap one group's host work with the other groups' kernels. */
+int mzmcts_readout_begin(mzmcts_engine *engine, void *stream);
 /* SelfPlay.select_action (self_play.py:223-246) for every env on its own RNG stream, using the
  * visit counts of the last readout.  temperature host f64[E] (0 = argmax, +inf = uniform);
  * action_out host i32[E] (action ids), slot_out optional host i32[E].  Inactive envs give -1. */

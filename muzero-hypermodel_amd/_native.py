@@ -74,6 +74,7 @@ PROTOTYPES = {
     "mzmcts_simulations_done": (ctypes.c_int32, [c_void]),
     "mzmcts_set_simulations_done": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_readout": (ctypes.c_int, [c_void, ctypes.POINTER(MzRootStats), c_void]),
+    "mzmcts_readout_begin": (ctypes.c_int, [c_void, c_void]),
     "mzmcts_sample_actions": (ctypes.c_int, [c_void, c_f64_p, c_i32_p, c_i32_p]),
     "mzmcts_search_statistics": (ctypes.c_int, [c_void, c_f64_p, c_f64_p]),
     "mzmcts_last_paths": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_void]),

@@ -2,11 +2,15 @@
 // device functions for one lane group, so a whole simulation (select -> dynamics -> prediction ->
 // expand/backup) can run inside one kernel without leaving the CU.
 //
-// Work split: output neuron o of a layer belongs to lane o mod G and is accumulated by that lane
-// alone, sequentially over the inputs with explicit fp32 FMAs, so a neuron's value does not depend
-// on G.  Layer inputs / outputs live in a small per-tree LDS scratch; the weights are staged once per
-// workgroup into LDS with every row padded to 16 bytes -- the G lanes of every group read the same
-// G rows, so the reads broadcast across the groups of the wave.
+// The network is evaluated as a short list of PHASES.  A phase is a set of up to three Linear layers
+// that do not depend on each other (e.g. the first layers of the reward, policy and value heads);
+// all their output neurons are dealt round-robin to the G lanes of the group.  Each neuron is one
+// sequential fp32 FMA chain over its inputs, so its value does not depend on G or on how phases are
+// formed.  A lane works on two neurons at a time and issues all their 16-byte LDS reads (inputs and
+// weight rows, 4 chunks = 16 inputs per block) before the first FMA: with one wavefront per SIMD there
+// is nobody else to hide an LDS round trip, so the number of dependent round trips per inference --
+// not the FLOP count -- is what this layout minimises.  Weights are staged once per workgroup into LDS
+// with every row padded to 16 bytes; layer inputs / outputs live in a per-tree LDS scratch.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -27,14 +31,29 @@ struct FcMlp {
     int32_t n_layers;
     FcLayer layer[kFcMaxLayers];
 };
-// scratch layout per tree, in floats: [x_in | t0 | t1 | raw | norm | reward | value | policy]; every
-// region starts 16-byte aligned and is padded to a multiple of 4 floats (pads hold zeros).
+struct FcJob {
+    int32_t in_pad, out, w_lds, b_lds;
+    int32_t x_off, y_off;    // scratch offsets (floats) of the input / output vectors
+    int32_t elu;             // hidden layer: ELU; last layer of an MLP: identity
+};
+struct FcPhase {
+    int32_t n_jobs, total_out;
+    FcJob job[3];
+};
+// Scratch per tree (floats, every region 16-byte aligned, pads kept at zero):
+//   [x_in | raw | norm | reward | value | policy | temps of head 0,1,2 (two each)]
 struct FcNet {
     int32_t obs, enc, A, F, support;
     int32_t n_weights;       // flat buffer
     int32_t n_weights_lds;   // padded on-chip copy
-    int32_t off_t0, off_t1, off_raw, off_norm, off_reward, off_value, off_policy, scratch_floats;
-    FcMlp repr, dyn, reward, policy, value;
+    int32_t off_raw, off_norm, off_reward, off_value, off_policy, scratch_floats;
+    // initial_inference: representation layers, rescale, then policy/value heads
+    int32_t n_init_pre, n_init_post;
+    FcPhase init_pre[kFcMaxLayers], init_post[kFcMaxLayers];
+    // recurrent_inference: dynamics layers, rescale, then reward/policy/value heads
+    int32_t n_rec_pre, n_rec_post;
+    FcPhase rec_pre[kFcMaxLayers], rec_post[kFcMaxLayers];
+    FcMlp repr, dyn, reward, policy, value;  // for weight staging
 };
 
 // LDS plan of the fused whole-move kernel (bytes from the start of dynamic LDS).
@@ -72,62 +91,95 @@ __device__ __forceinline__ void stage_fc_weights(const FcNet& net, const float* 
     stage_mlp_weights(net.value, flat, w_lds, tid, nthreads);
 }
 
-// models.py:626-638 mlp(): Linear (+ELU between layers, identity at the end).
-// `w` is the padded on-chip weight copy; `x` (padded with zeros to a multiple of 4) must be visible to
-// the whole group on entry; `y` is visible to the whole group on exit, its pad zeroed.
-// Each output neuron is one sequential fp32 FMA chain over its inputs (so its value is independent of
-// G); a lane runs up to four neurons at a time for instruction-level parallelism, with 16-byte LDS
-// reads of the shared input vector and of each weight row.
-template <int G>
-__device__ __forceinline__ void mlp_forward(const FcMlp& m, const float* w, const float* x, float* y, float* t0,
-                                            float* t1, int j) {
-    const float* cur = x;
-    for (int l = 0; l < m.n_layers; ++l) {
-        const FcLayer L = m.layer[l];
-        const bool last = l == m.n_layers - 1;
-        float* dst = last ? y : ((l & 1) ? t1 : t0);
-        const int chunks = L.in_pad >> 2;
-        const float4* x4 = reinterpret_cast<const float4*>(cur);
-        for (int o0 = j; o0 < L.out; o0 += 4 * G) {
-            const float4* row[4];
-            bool live[4];
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int o = o0 + u * G;
-                live[u] = o < L.out;
-                row[u] = reinterpret_cast<const float4*>(w + L.w_lds + (live[u] ? o : o0) * L.in_pad);
-            }
-            for (int c = 0; c < chunks; ++c) {
-                const float4 xv = x4[c];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (live[u]) {
-                        const float4 wv = row[u][c];
-                        acc[u] = fmaf(wv.x, xv.x, acc[u]);
-                        acc[u] = fmaf(wv.y, xv.y, acc[u]);
-                        acc[u] = fmaf(wv.z, xv.z, acc[u]);
-                        acc[u] = fmaf(wv.w, xv.w, acc[u]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (live[u]) {
-                    const int o = o0 + u * G;
-                    float v = acc[u] + w[L.b_lds + o];
-                    if (!last) v = v > 0.f ? v : expm1f(v);  // ELU(alpha = 1)
-                    dst[o] = v;
-                }
-            }
-        }
-        for (int o = L.out + j; o < ((L.out + 3) & ~3); o += G) dst[o] = 0.f;  // keep the pad at zero
-        group_memory_fence();
-        cur = dst;
-    }
+struct NeuronRef {
+    const float4* row;  // weight row (padded)
+    const float4* x;    // input vector (padded)
+    float* y;           // where the activation goes
+    float bias;
+    int chunks;         // in_pad / 4; 0 = no neuron
+    bool elu;
+};
+
+// Which job / row neuron n of a phase is.  The phase descriptor is a kernel argument (wave-uniform,
+// held in SGPRs); the job is picked with per-lane selects, never with a per-lane index into it (that
+// would turn every field access into a memory load from the kernarg segment).
+__device__ __forceinline__ NeuronRef locate_neuron(const FcPhase& ph, const float* w, float* scratch, int n) {
+    const bool live = n < ph.total_out;
+    const FcJob j0 = ph.job[0], j1 = ph.job[1], j2 = ph.job[2];
+    const bool past0 = ph.n_jobs > 1 && n >= j0.out;
+    const bool past1 = ph.n_jobs > 2 && n >= j0.out + j1.out;
+    int o = past1 ? n - j0.out - j1.out : (past0 ? n - j0.out : n);
+    const int in_pad = past1 ? j2.in_pad : (past0 ? j1.in_pad : j0.in_pad);
+    const int w_lds = past1 ? j2.w_lds : (past0 ? j1.w_lds : j0.w_lds);
+    const int b_lds = past1 ? j2.b_lds : (past0 ? j1.b_lds : j0.b_lds);
+    const int x_off = past1 ? j2.x_off : (past0 ? j1.x_off : j0.x_off);
+    const int y_off = past1 ? j2.y_off : (past0 ? j1.y_off : j0.y_off);
+    const int elu = past1 ? j2.elu : (past0 ? j1.elu : j0.elu);
+    o = live ? o : 0;  // a lane without a neuron still forms valid addresses (row 0) and never stores
+    NeuronRef r;
+    r.row = reinterpret_cast<const float4*>(w + w_lds + o * in_pad);
+    r.x = reinterpret_cast<const float4*>(scratch + x_off);
+    r.y = scratch + y_off + o;
+    r.bias = w[b_lds + o];
+    r.chunks = live ? (in_pad >> 2) : 0;
+    r.elu = elu != 0;
+    return r;
 }
 
-// Row-wise min-max rescale to [0,1] (models.py:137-145, 161-168): raw -> norm (pad zeroed).
+__device__ __forceinline__ float fma4(const float4& wv, const float4& xv, float acc) {
+    acc = fmaf(wv.x, xv.x, acc);
+    acc = fmaf(wv.y, xv.y, acc);
+    acc = fmaf(wv.z, xv.z, acc);
+    acc = fmaf(wv.w, xv.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ float elu_or_identity(float v, bool elu) {
+    const float e = expm1f(fminf(v, 0.f));  // ELU(alpha = 1) on the negative side
+    return (elu && !(v > 0.f)) ? e : v;
+}
+
+// models.py:626-638, one phase: Linear (+ELU on hidden layers) for every neuron of up to three
+// independent layers.  Inputs must be visible to the group on entry; outputs are on exit.
+// Loads are unconditional (indices clamped into the row) so that they stay 16-byte LDS reads issued
+// back to back; chunks beyond a neuron's width are discarded with a select, not a branch.
+template <int G>
+__device__ __forceinline__ void run_phase(const FcPhase& ph, const float* w, float* scratch, int j) {
+    constexpr int KB = 4;  // chunks (of 4 inputs) whose loads are issued together
+    for (int n0 = j; n0 < ph.total_out; n0 += 2 * G) {
+        const NeuronRef a = locate_neuron(ph, w, scratch, n0);
+        const NeuronRef b = locate_neuron(ph, w, scratch, n0 + G);
+        float acc_a = 0.f, acc_b = 0.f;
+        const int chunks = a.chunks > b.chunks ? a.chunks : b.chunks;
+        const int last_a = a.chunks > 0 ? a.chunks - 1 : 0, last_b = b.chunks > 0 ? b.chunks - 1 : 0;
+        for (int c0 = 0; c0 < chunks; c0 += KB) {
+            float4 wa[KB], xa[KB], wb[KB], xb[KB];
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int ia = (c0 + u < last_a) ? c0 + u : last_a;
+                const int ib = (c0 + u < last_b) ? c0 + u : last_b;
+                wa[u] = a.row[ia];
+                xa[u] = a.x[ia];
+                wb[u] = b.row[ib];
+                xb[u] = b.x[ib];
+            }
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const float ta = fma4(wa[u], xa[u], acc_a);
+                const float tb = fma4(wb[u], xb[u], acc_b);
+                acc_a = (c0 + u < a.chunks) ? ta : acc_a;
+                acc_b = (c0 + u < b.chunks) ? tb : acc_b;
+            }
+        }
+        const float va = elu_or_identity(acc_a + a.bias, a.elu);
+        const float vb = elu_or_identity(acc_b + b.bias, b.elu);
+        if (a.chunks) *a.y = va;
+        if (b.chunks) *b.y = vb;
+    }
+    group_memory_fence();
+}
+
+// Row-wise min-max rescale to [0,1] (models.py:137-145, 161-168): raw -> norm.
 template <int G>
 __device__ __forceinline__ void unit_rescale(const float* raw, float* norm, int n, int j) {
     float mn = INFINITY, mx = -INFINITY;
@@ -140,7 +192,13 @@ __device__ __forceinline__ void unit_rescale(const float* raw, float* norm, int 
     float scale = mx - mn;
     if (scale < 1e-5f) scale += 1e-5f;
     for (int i = j; i < n; i += G) norm[i] = (raw[i] - mn) / scale;
-    for (int i = n + j; i < ((n + 3) & ~3); i += G) norm[i] = 0.f;
+    group_memory_fence();
+}
+
+// Zero the whole scratch once (pads must read as zero; regions only ever receive finite activations).
+template <int G>
+__device__ __forceinline__ void fc_clear_scratch(const FcNet& net, float* scratch, int j) {
+    for (int i = j; i < net.scratch_floats; i += G) scratch[i] = 0.f;
     group_memory_fence();
 }
 
@@ -151,16 +209,14 @@ __device__ __forceinline__ void fc_initial(const FcNet& net, const float* w, flo
     float* x = scratch;
     for (int i = j; i < ((net.obs + 3) & ~3); i += G) x[i] = (i < net.obs) ? obs[i] : 0.f;
     group_memory_fence();
-    mlp_forward<G>(net.repr, w, x, scratch + net.off_raw, scratch + net.off_t0, scratch + net.off_t1, j);
+    for (int ph = 0; ph < net.n_init_pre; ++ph) run_phase<G>(net.init_pre[ph], w, scratch, j);
     unit_rescale<G>(scratch + net.off_raw, scratch + net.off_norm, net.enc, j);
-    mlp_forward<G>(net.policy, w, scratch + net.off_norm, scratch + net.off_policy, scratch + net.off_t0,
-                   scratch + net.off_t1, j);
-    mlp_forward<G>(net.value, w, scratch + net.off_norm, scratch + net.off_value, scratch + net.off_t0,
-                   scratch + net.off_t1, j);
+    for (int ph = 0; ph < net.n_init_post; ++ph) run_phase<G>(net.init_post[ph], w, scratch, j);
 }
 
 // models.py:147-170, 192-195 recurrent_inference.  On exit scratch holds norm (next hidden state),
-// reward / value / policy logits.
+// reward / value / policy logits.  The reward head reads the UN-normalised next state
+// (models.py:157-159), so all three heads can run side by side once the rescale is done.
 template <int G>
 __device__ __forceinline__ void fc_recurrent(const FcNet& net, const float* w, float* scratch, const float* hidden,
                                              int action, int j) {
@@ -169,15 +225,9 @@ __device__ __forceinline__ void fc_recurrent(const FcNet& net, const float* w, f
     // one-hot action, then zeros up to the padded width
     for (int a = j; net.enc + a < ((net.enc + net.A + 3) & ~3); a += G) x[net.enc + a] = (a == action) ? 1.f : 0.f;
     group_memory_fence();
-    mlp_forward<G>(net.dyn, w, x, scratch + net.off_raw, scratch + net.off_t0, scratch + net.off_t1, j);
-    // reward head reads the UN-normalised next state (models.py:157-159)
-    mlp_forward<G>(net.reward, w, scratch + net.off_raw, scratch + net.off_reward, scratch + net.off_t0,
-                   scratch + net.off_t1, j);
+    for (int ph = 0; ph < net.n_rec_pre; ++ph) run_phase<G>(net.rec_pre[ph], w, scratch, j);
     unit_rescale<G>(scratch + net.off_raw, scratch + net.off_norm, net.enc, j);
-    mlp_forward<G>(net.policy, w, scratch + net.off_norm, scratch + net.off_policy, scratch + net.off_t0,
-                   scratch + net.off_t1, j);
-    mlp_forward<G>(net.value, w, scratch + net.off_norm, scratch + net.off_value, scratch + net.off_t0,
-                   scratch + net.off_t1, j);
+    for (int ph = 0; ph < net.n_rec_post; ++ph) run_phase<G>(net.rec_post[ph], w, scratch, j);
 }
 
 }  // namespace mz

@@ -260,9 +260,10 @@ __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, i
         value = inj_value[e];
         reward_f = static_cast<float>(inj_reward[e]);
     } else {
-        value = static_cast<double>(
-            support_to_scalar_group<G>(value_logits + static_cast<size_t>(e) * p.F, p.F, p.support, j));
-        reward_f = support_to_scalar_group<G>(reward_logits + static_cast<size_t>(e) * p.F, p.F, p.support, j);
+        float value_f;
+        support_to_scalar_pair<G>(value_logits + static_cast<size_t>(e) * p.F, reward_logits + static_cast<size_t>(e) * p.F,
+                                  p.F, p.support, j, value_f, reward_f);
+        value = static_cast<double>(value_f);
     }
     float logit[CH];
     bool valid[CH];
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(kThreads) void fc_inference_kernel(FcNet net, const
     const int j = threadIdx.x % G;
     if (e >= E) return;
     float* scratch = fc_smem + ((net.n_weights_lds + 3) & ~3) + static_cast<size_t>(tree_in_block) * net.scratch_floats;
+    fc_clear_scratch<G>(net, scratch, j);
     if (INITIAL) {
         fc_initial<G>(net, w_lds, scratch, in + static_cast<size_t>(e) * net.obs, j);
         for (int i = j; i < net.F; i += G)
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
     const bool two_player = p.P == 2;
 
     // ---- root: initial inference, root.expand over the legal actions, exploration noise ----------
+    fc_clear_scratch<G>(net, scratch, j);
     fc_initial<G>(net, w_lds, scratch, observations + static_cast<size_t>(e) * net.obs, j);
     const float predicted = support_to_scalar_group<G>(scratch + net.off_value, net.F, net.support, j);
     {
@@ -432,9 +435,10 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
                                          : p.hidden + (static_cast<size_t>(d.parent) * p.E + e) * H;
         fc_recurrent<G>(net, w_lds, scratch, parent_hidden, action, j);
         MZ_STAMP(3);
-        const double value = static_cast<double>(
-            support_to_scalar_group<G>(scratch + net.off_value, net.F, net.support, j));
-        const float reward_f = support_to_scalar_group<G>(scratch + net.off_reward, net.F, net.support, j);
+        float value_f, reward_f;
+        support_to_scalar_pair<G>(scratch + net.off_value, scratch + net.off_reward, net.F, net.support, j, value_f,
+                                  reward_f);
+        const double value = static_cast<double>(value_f);
         float logit[CH];
         bool valid[CH];
         double prior[CH];

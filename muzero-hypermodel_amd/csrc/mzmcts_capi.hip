@@ -9,7 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <initializer_list>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -58,6 +64,94 @@ struct EventPair {
     hipEvent_t begin, end;
     int kind;
 };
+
+// Persistent, process-wide worker pool for the per-env host work of a move (Dirichlet draws, action
+// sampling, readout unpacking).  Workers spin briefly on the job generation before sleeping: in a
+// self-play loop the next job arrives within microseconds, and a condition-variable wake-up costs more
+// than the work itself at a few thousand envs.
+class WorkerPool {
+  public:
+    explicit WorkerPool(int workers) {
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+            generation_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int size() const { return static_cast<int>(threads_.size()); }
+    // body(lo, hi) over [0, n) split into size()+1 contiguous chunks; the caller runs the last one.
+    void run(int n, const std::function<void(int, int)>& body) {
+        std::lock_guard<std::mutex> serial(run_mu_);  // one job at a time (engines share the pool)
+        const int parts = size() + 1;
+        const int chunk = (n + parts - 1) / parts;
+        body_ = &body;
+        n_ = n;
+        chunk_ = chunk;
+        pending_.store(size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            generation_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        const int lo = size() * chunk;
+        if (lo < n) body(lo, n);
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        body_ = nullptr;
+    }
+
+  private:
+    void loop(int index) {
+        uint64_t seen = 0;
+        for (;;) {
+            // spin for the next job, then fall back to sleeping
+            bool have = false;
+            for (int spin = 0; spin < 20000; ++spin) {
+                if (generation_.load(std::memory_order_acquire) != seen) {
+                    have = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            if (!have) {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+            }
+            seen = generation_.load(std::memory_order_acquire);
+            if (stop_) return;
+            const std::function<void(int, int)>* body = body_;
+            const int lo = index * chunk_, hi = std::min(n_, lo + chunk_);
+            if (body && lo < hi) (*body)(lo, hi);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_;
+    const std::function<void(int, int)>* body_ = nullptr;
+    int n_ = 0, chunk_ = 0;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> generation_{0};
+    bool stop_ = false;
+};
+
+int host_worker_count(int n_items) {
+    int hw = static_cast<int>(std::thread::hardware_concurrency());
+    if (hw <= 0) hw = 1;
+    if (const char* env = std::getenv("MZMCTS_HOST_THREADS")) hw = std::max(1, std::atoi(env));
+    (void)n_items;
+    return std::max(0, std::min(hw, 8) - 1);
+}
+
+WorkerPool& shared_pool() {
+    static WorkerPool pool(host_worker_count(0));
+    return pool;
+}
+
 }  // namespace
 
 struct mzmcts_engine {
@@ -114,6 +208,27 @@ struct mzmcts_engine {
 
     std::vector<void*> device_allocs;
     std::vector<void*> pinned_allocs;
+
+    // packed per-move upload ([legal | num_legal | to_play | rng_skip | noise]) and per-tree download
+    uint8_t* h_upload = nullptr;
+    uint8_t* d_upload = nullptr;
+    size_t upload_bytes = 0, upload_bytes_no_noise = 0;
+    uint8_t* h_download = nullptr;
+    uint8_t* d_download = nullptr;
+    size_t download_bytes = 0;
+    bool tie_words_applied = false;
+
+    // pending asynchronous readout (mzmcts_readout_begin)
+    hipEvent_t readout_event = nullptr;
+    bool readout_pending = false;
+
+    void for_each_env(const std::function<void(int, int)>& body) {
+        WorkerPool& pool = shared_pool();
+        if (pool.size() > 0 && p.E >= 512)
+            pool.run(p.E, body);
+        else
+            body(0, p.E);
+    }
 };
 
 namespace {
@@ -182,23 +297,6 @@ struct ProfScope {
     const mz::LaunchTiming* get() const { return timing.start ? &timing : nullptr; }
 };
 
-void parallel_for(int n, int max_threads, const std::function<void(int, int)>& body) {
-    int hw = static_cast<int>(std::thread::hardware_concurrency());
-    if (hw <= 0) hw = 1;
-    int threads = std::min(std::min(hw, max_threads), std::max(1, n / 512));
-    if (threads <= 1) {
-        body(0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const int chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        const int lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        pool.emplace_back([=, &body] { body(lo, hi); });
-    }
-    for (auto& th : pool) th.join();
-}
 }  // namespace
 
 extern "C" {
@@ -279,21 +377,58 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     p.path_ties = nullptr;
     if ((rc = dev_alloc(eng, &p.path_len, E))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &p.leaf_parent, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.min_max, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.root_value_sum, E))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &p.root_reward, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.root_predicted, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.root_children, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.root_to_play, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.root_action, static_cast<size_t>(E) * A))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.max_depth, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.depth_sum, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.tie_words, E))) return cleanup_on(rc);
+    {
+        // per-move upload block: [legal i32 E*A | num_legal i32 E | to_play i32 E | rng_skip u32 E | noise f64 E*A]
+        auto align8 = [](size_t v) { return (v + 7) / 8 * 8; };
+        const size_t o_legal = 0;
+        const size_t o_nlegal = o_legal + sizeof(int32_t) * static_cast<size_t>(E) * A;
+        const size_t o_to_play = o_nlegal + sizeof(int32_t) * E;
+        const size_t o_skip = o_to_play + sizeof(int32_t) * E;
+        const size_t o_noise = align8(o_skip + sizeof(uint32_t) * E);
+        eng->upload_bytes_no_noise = o_noise;
+        eng->upload_bytes = o_noise + sizeof(double) * static_cast<size_t>(E) * A;
+        if ((rc = dev_alloc(eng, &eng->d_upload, eng->upload_bytes))) return cleanup_on(rc);
+        if ((rc = pinned_alloc(eng, &eng->h_upload, eng->upload_bytes))) return cleanup_on(rc);
+        p.root_action = reinterpret_cast<int32_t*>(eng->d_upload + o_legal);
+        p.root_children = reinterpret_cast<int32_t*>(eng->d_upload + o_nlegal);
+        p.root_to_play = reinterpret_cast<int32_t*>(eng->d_upload + o_to_play);
+        eng->d_skip = reinterpret_cast<uint32_t*>(eng->d_upload + o_skip);
+        eng->d_noise = reinterpret_cast<double*>(eng->d_upload + o_noise);
+        eng->h_legal = reinterpret_cast<int32_t*>(eng->h_upload + o_legal);
+        eng->h_nlegal = reinterpret_cast<int32_t*>(eng->h_upload + o_nlegal);
+        eng->h_to_play = reinterpret_cast<int32_t*>(eng->h_upload + o_to_play);
+        eng->h_skip = reinterpret_cast<uint32_t*>(eng->h_upload + o_skip);
+        eng->h_noise = reinterpret_cast<double*>(eng->h_upload + o_noise);
+        // per-tree download block: [root_value_sum f64 E | min_max 2xf64 E | depth_sum i64 E |
+        //                           root_predicted f32 E | max_depth i32 E | tie_words u32 E | error_flag i32 x4]
+        const size_t o_rvs = 0;
+        const size_t o_mm = o_rvs + sizeof(double) * E;
+        const size_t o_ds = o_mm + sizeof(mz::MinMax) * E;
+        const size_t o_pred = o_ds + sizeof(int64_t) * E;
+        const size_t o_md = o_pred + sizeof(float) * E;
+        const size_t o_tw = o_md + sizeof(int32_t) * E;
+        const size_t o_err = o_tw + sizeof(uint32_t) * E;
+        eng->download_bytes = o_err + sizeof(int32_t) * 4;
+        if ((rc = dev_alloc(eng, &eng->d_download, eng->download_bytes))) return cleanup_on(rc);
+        if ((rc = pinned_alloc(eng, &eng->h_download, eng->download_bytes))) return cleanup_on(rc);
+        p.root_value_sum = reinterpret_cast<double*>(eng->d_download + o_rvs);
+        p.min_max = reinterpret_cast<mz::MinMax*>(eng->d_download + o_mm);
+        p.depth_sum = reinterpret_cast<int64_t*>(eng->d_download + o_ds);
+        p.root_predicted = reinterpret_cast<float*>(eng->d_download + o_pred);
+        p.max_depth = reinterpret_cast<int32_t*>(eng->d_download + o_md);
+        p.tie_words = reinterpret_cast<uint32_t*>(eng->d_download + o_tw);
+        p.error_flag = reinterpret_cast<int32_t*>(eng->d_download + o_err);
+        eng->h_root_value_sum = reinterpret_cast<double*>(eng->h_download + o_rvs);
+        eng->h_min_max = reinterpret_cast<mz::MinMax*>(eng->h_download + o_mm);
+        eng->h_depth_sum = reinterpret_cast<int64_t*>(eng->h_download + o_ds);
+        eng->h_root_predicted = reinterpret_cast<float*>(eng->h_download + o_pred);
+        eng->h_max_depth = reinterpret_cast<int32_t*>(eng->h_download + o_md);
+        eng->h_tie_words = reinterpret_cast<uint32_t*>(eng->h_download + o_tw);
+        eng->h_error_flag = reinterpret_cast<int32_t*>(eng->h_download + o_err);
+    }
     if ((rc = dev_alloc(eng, &p.mt_key, static_cast<size_t>(E) * mz::kMtN))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &p.mt_pos, E))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &p.error_flag, 4))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &eng->d_noise, static_cast<size_t>(E) * A))) return cleanup_on(rc);
-    if ((rc = dev_alloc(eng, &eng->d_skip, E))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &eng->d_seeds, E))) return cleanup_on(rc);
 
     // pb_c tables: host libm, the same log/sqrt Python's math module calls (self_play.py:385-391)
@@ -311,19 +446,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         p.pbc_sqrt = d_tab + K;
     }
 
-    if ((rc = pinned_alloc(eng, &eng->h_legal, static_cast<size_t>(E) * A))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_nlegal, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_to_play, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_noise, static_cast<size_t>(E) * A))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_skip, E))) return cleanup_on(rc);
     if ((rc = pinned_alloc(eng, &eng->h_slab0, static_cast<size_t>(E) * p.block_stride))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_root_value_sum, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_root_predicted, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_max_depth, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_depth_sum, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_tie_words, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_min_max, E))) return cleanup_on(rc);
-    if ((rc = pinned_alloc(eng, &eng->h_error_flag, 4))) return cleanup_on(rc);
 
     eng->streams.resize(E);
     eng->lag.assign(E, 0u);
@@ -350,6 +473,7 @@ void mzmcts_destroy(mzmcts_engine* eng) {
         (void)hipEventDestroy(ev.begin);
         (void)hipEventDestroy(ev.end);
     }
+    if (eng->readout_event) (void)hipEventDestroy(eng->readout_event);
     for (void* ptr : eng->device_allocs) (void)hipFree(ptr);
     for (void* ptr : eng->pinned_allocs) (void)hipHostFree(ptr);
     delete eng;
@@ -359,7 +483,7 @@ int mzmcts_seed(mzmcts_engine* eng, const uint32_t* seeds, void* stream_) {
     if (!eng || !seeds) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_seed: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int E = eng->p.E;
-    parallel_for(E, 16, [&](int lo, int hi) {
+    eng->for_each_env([&](int lo, int hi) {
         for (int e = lo; e < hi; ++e) eng->streams[e].seed(seeds[e]);
     });
     std::fill(eng->lag.begin(), eng->lag.end(), 0u);
@@ -417,11 +541,14 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
                 return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
         }
     }
+    const bool trace = std::getenv("MZMCTS_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = trace ? now() : 0.0;
     std::memcpy(eng->h_legal, legal, sizeof(int32_t) * static_cast<size_t>(E) * A);
     std::memcpy(eng->h_nlegal, num_legal, sizeof(int32_t) * E);
     std::memcpy(eng->h_to_play, to_play, sizeof(int32_t) * E);
     const double alpha = eng->cfg.root_dirichlet_alpha;
-    parallel_for(E, 16, [&](int lo, int hi) {
+    eng->for_each_env([&](int lo, int hi) {
         for (int e = lo; e < hi; ++e) {
             const int n = eng->h_nlegal[e];
             double* row = eng->h_noise + static_cast<size_t>(e) * A;
@@ -440,17 +567,16 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
             eng->lag[e] = 0;
         }
     });
+    const double t_dirichlet = trace ? now() : 0.0;
     if (noise_out) std::memcpy(noise_out, eng->h_noise, sizeof(double) * static_cast<size_t>(E) * A);
     eng->noise_this_search = add_noise != 0;
-    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_action, eng->h_legal, sizeof(int32_t) * static_cast<size_t>(E) * A,
+    MZ_HIP(eng, hipMemcpyAsync(eng->d_upload, eng->h_upload, add_noise ? eng->upload_bytes : eng->upload_bytes_no_noise,
                                hipMemcpyHostToDevice, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_children, eng->h_nlegal, sizeof(int32_t) * E, hipMemcpyHostToDevice, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->p.root_to_play, eng->h_to_play, sizeof(int32_t) * E, hipMemcpyHostToDevice, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->d_skip, eng->h_skip, sizeof(uint32_t) * E, hipMemcpyHostToDevice, stream));
-    if (add_noise)
-        MZ_HIP(eng, hipMemcpyAsync(eng->d_noise, eng->h_noise, sizeof(double) * static_cast<size_t>(E) * A,
-                                   hipMemcpyHostToDevice, stream));
+    if (trace)
+        std::fprintf(stderr, "[mzmcts] begin_search E=%d: host prep+dirichlet %.1f us, memcpy+enqueue %.1f us\n", E,
+                     t_dirichlet - t_start, now() - t_dirichlet);
     eng->search_begun = true;
+    eng->tie_words_applied = false;
     eng->roots_ready = false;
     eng->have_readout = false;
     eng->sim = 0;
@@ -548,21 +674,39 @@ int mzmcts_set_simulations_done(mzmcts_engine* eng, int32_t n) {
     return MZMCTS_OK;
 }
 
+static int enqueue_readout_copies(mzmcts_engine* eng, hipStream_t stream) {
+    const mz::TreeParams& p = eng->p;
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(p.E) * p.block_stride, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_download, eng->d_download, eng->download_bytes, hipMemcpyDeviceToHost, stream));
+    return MZMCTS_OK;
+}
+
+int mzmcts_readout_begin(mzmcts_engine* eng, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (!eng->roots_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_readout_begin called before expand_roots");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!eng->readout_event) MZ_HIP(eng, hipEventCreateWithFlags(&eng->readout_event, hipEventDisableTiming));
+    int rc = enqueue_readout_copies(eng, stream);
+    if (rc) return rc;
+    MZ_HIP(eng, hipEventRecord(eng->readout_event, stream));
+    eng->readout_pending = true;
+    return MZMCTS_OK;
+}
+
 int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* stream_) {
     if (!eng) return MZMCTS_ERR_INVALID;
     if (!eng->roots_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_readout called before expand_roots");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const mz::TreeParams& p = eng->p;
     const int E = p.E, A = p.A;
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(E) * p.block_stride, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_root_value_sum, p.root_value_sum, sizeof(double) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_root_predicted, p.root_predicted, sizeof(float) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_max_depth, p.max_depth, sizeof(int32_t) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_depth_sum, p.depth_sum, sizeof(int64_t) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_tie_words, p.tie_words, sizeof(uint32_t) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_min_max, p.min_max, sizeof(mz::MinMax) * E, hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipStreamSynchronize(stream));
+    if (eng->readout_pending) {
+        MZ_HIP(eng, hipEventSynchronize(eng->readout_event));
+        eng->readout_pending = false;
+    } else {
+        int rc = enqueue_readout_copies(eng, stream);
+        if (rc) return rc;
+        MZ_HIP(eng, hipStreamSynchronize(stream));
+    }
     if (eng->h_error_flag[0] != 0)
         return fail(eng, MZMCTS_ERR_INVALID,
                     (eng->h_error_flag[0] & 2) ? "device error flag set: tree links are inconsistent (descent ran past the "
@@ -570,51 +714,57 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
                                                : "device error flag set: a UCB score was NaN (no maximum to select)");
 
     const int sims = eng->sim;
-    int64_t depth_total = 0, active = 0;
-    for (int e = 0; e < E; ++e) {
-        const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.block_stride;
-        const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
-        const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
-        const int n = eng->h_nlegal[e];
-        const bool is_active = n > 0;
-        for (int i = 0; i < A; ++i) {
-            const size_t o = static_cast<size_t>(e) * A + i;
-            const bool live = i < n;
-            eng->last_visits[o] = live ? lk[i].visits : 0;
+    const bool first = !eng->tie_words_applied;
+    std::atomic<int64_t> depth_total{0}, active{0};
+    eng->for_each_env([&](int lo, int hi) {
+        int64_t local_depth = 0, local_active = 0;
+        for (int e = lo; e < hi; ++e) {
+            const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.block_stride;
+            const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
+            const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
+            const int n = eng->h_nlegal[e];
+            const bool is_active = n > 0;
+            for (int i = 0; i < A; ++i) {
+                const size_t o = static_cast<size_t>(e) * A + i;
+                const bool live = i < n;
+                eng->last_visits[o] = live ? lk[i].visits : 0;
+                if (out) {
+                    if (out->visits) out->visits[o] = live ? lk[i].visits : 0;
+                    if (out->child_value_sum) out->child_value_sum[o] = live ? st[i].value_sum : 0.0;
+                    if (out->child_prior) out->child_prior[o] = live ? st[i].prior : 0.0;
+                    if (out->child_reward) out->child_reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
+                    if (out->child_expanded) out->child_expanded[o] = (live && lk[i].child_node >= 0) ? 1 : 0;
+                }
+            }
+            eng->last_root_value_sum[e] = is_active ? eng->h_root_value_sum[e] : 0.0;
+            eng->last_root_visits[e] = is_active ? sims : 0;
+            if (is_active) {
+                // the tie-breaks ran on the device copy of the stream: bring the host mirror level (once)
+                if (first) eng->streams[e].skip(eng->h_tie_words[e]);
+                local_depth += eng->h_depth_sum[e];
+                ++local_active;
+            }
             if (out) {
-                if (out->visits) out->visits[o] = live ? lk[i].visits : 0;
-                if (out->child_value_sum) out->child_value_sum[o] = live ? st[i].value_sum : 0.0;
-                if (out->child_prior) out->child_prior[o] = live ? st[i].prior : 0.0;
-                if (out->child_reward) out->child_reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
-                if (out->child_expanded) out->child_expanded[o] = (live && lk[i].child_node >= 0) ? 1 : 0;
+                if (out->root_value_sum) out->root_value_sum[e] = eng->last_root_value_sum[e];
+                if (out->root_visits) out->root_visits[e] = eng->last_root_visits[e];
+                if (out->max_tree_depth) out->max_tree_depth[e] = is_active ? eng->h_max_depth[e] : 0;
+                if (out->root_predicted_value) out->root_predicted_value[e] = static_cast<double>(eng->h_root_predicted[e]);
+                if (out->min_max) {
+                    out->min_max[2 * e] = eng->h_min_max[e].minimum;
+                    out->min_max[2 * e + 1] = eng->h_min_max[e].maximum;
+                }
+                if (out->depth_sum) out->depth_sum[e] = is_active ? eng->h_depth_sum[e] : 0;
+                if (out->tie_break_words) out->tie_break_words[e] = is_active ? eng->h_tie_words[e] : 0u;
             }
         }
-        eng->last_root_value_sum[e] = is_active ? eng->h_root_value_sum[e] : 0.0;
-        eng->last_root_visits[e] = is_active ? sims : 0;
-        if (is_active) {
-            // the tie-breaks ran on the device copy of the stream: bring the host mirror level
-            eng->streams[e].skip(eng->h_tie_words[e]);
-            depth_total += eng->h_depth_sum[e];
-            ++active;
-        }
-        if (out) {
-            if (out->root_value_sum) out->root_value_sum[e] = eng->last_root_value_sum[e];
-            if (out->root_visits) out->root_visits[e] = eng->last_root_visits[e];
-            if (out->max_tree_depth) out->max_tree_depth[e] = is_active ? eng->h_max_depth[e] : 0;
-            if (out->root_predicted_value) out->root_predicted_value[e] = static_cast<double>(eng->h_root_predicted[e]);
-            if (out->min_max) {
-                out->min_max[2 * e] = eng->h_min_max[e].minimum;
-                out->min_max[2 * e + 1] = eng->h_min_max[e].maximum;
-            }
-            if (out->depth_sum) out->depth_sum[e] = is_active ? eng->h_depth_sum[e] : 0;
-            if (out->tie_break_words) out->tie_break_words[e] = is_active ? eng->h_tie_words[e] : 0u;
-        }
+        depth_total.fetch_add(local_depth, std::memory_order_relaxed);
+        active.fetch_add(local_active, std::memory_order_relaxed);
+    });
+    if (first) {
+        eng->prof.select_depth_sum += depth_total.load();
+        eng->prof.simulations += active.load() * sims;
     }
-    eng->prof.select_depth_sum += depth_total;
-    eng->prof.simulations += active * sims;
-    // a tree's tie words must not be applied twice if readout is called again
-    MZ_HIP(eng, hipMemsetAsync(p.tie_words, 0, sizeof(uint32_t) * E, stream));
-    MZ_HIP(eng, hipMemsetAsync(p.depth_sum, 0, sizeof(int64_t) * E, stream));
+    eng->tie_words_applied = true;
     eng->have_readout = true;
     return MZMCTS_OK;
 }
@@ -624,7 +774,7 @@ int mzmcts_sample_actions(mzmcts_engine* eng, const double* temperature, int32_t
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_sample_actions: null argument");
     if (!eng->have_readout) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_sample_actions called before readout");
     const int E = eng->p.E, A = eng->p.A;
-    parallel_for(E, 16, [&](int lo, int hi) {
+    eng->for_each_env([&](int lo, int hi) {
         for (int e = lo; e < hi; ++e) {
             const int n = eng->h_nlegal[e];
             if (n == 0) {
@@ -782,12 +932,9 @@ int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_configure: n_weights does not match the layer description");
     net.n_weights = cursor;
     net.n_weights_lds = lds_cursor;
+    // scratch regions (floats, 16-byte aligned): x_in | raw | norm | reward | value | policy | 3 heads x 2 temps
     auto pad4 = [](int v) { return (v + 3) / 4 * 4; };
     int off = pad4(std::max(net.obs, net.enc + net.A));
-    net.off_t0 = off;
-    off += pad4(max_hidden);
-    net.off_t1 = off;
-    off += pad4(max_hidden);
     net.off_raw = off;
     off += pad4(net.enc);
     net.off_norm = off;
@@ -798,7 +945,63 @@ int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float
     off += pad4(net.F);
     net.off_policy = off;
     off += pad4(net.A);
+    int temp[3][2];
+    for (int h = 0; h < 3; ++h)
+        for (int t = 0; t < 2; ++t) {
+            temp[h][t] = off;
+            off += pad4(max_hidden);
+        }
     net.scratch_floats = off;
+    auto job_of = [&](const mz::FcMlp& m, int l, int x_first, int y_last, int head) {
+        mz::FcJob jb{};
+        const mz::FcLayer& L = m.layer[l];
+        jb.in_pad = L.in_pad;
+        jb.out = L.out;
+        jb.w_lds = L.w_lds;
+        jb.b_lds = L.b_lds;
+        jb.x_off = (l == 0) ? x_first : temp[head][(l - 1) & 1];
+        jb.y_off = (l == m.n_layers - 1) ? y_last : temp[head][l & 1];
+        jb.elu = (l == m.n_layers - 1) ? 0 : 1;
+        return jb;
+    };
+    auto chain = [&](const mz::FcMlp& m, int x_first, int y_last, mz::FcPhase* phases, int32_t* count) {
+        *count = m.n_layers;
+        for (int l = 0; l < m.n_layers; ++l) {
+            phases[l].n_jobs = 1;
+            phases[l].job[0] = job_of(m, l, x_first, y_last, 0);
+            phases[l].total_out = phases[l].job[0].out;
+        }
+    };
+    struct Head {
+        const mz::FcMlp* mlp;
+        int x_first, y_last;
+    };
+    auto heads = [&](std::initializer_list<Head> hs, mz::FcPhase* phases, int32_t* count) {
+        int depth = 0;
+        for (const Head& h : hs) depth = std::max(depth, static_cast<int>(h.mlp->n_layers));
+        *count = depth;
+        for (int l = 0; l < depth; ++l) {
+            phases[l].n_jobs = 0;
+            phases[l].total_out = 0;
+            int head_index = 0;
+            for (const Head& h : hs) {
+                if (l < h.mlp->n_layers) {
+                    phases[l].job[phases[l].n_jobs] = job_of(*h.mlp, l, h.x_first, h.y_last, head_index);
+                    phases[l].total_out += h.mlp->layer[l].out;
+                    phases[l].n_jobs += 1;
+                }
+                ++head_index;
+            }
+        }
+    };
+    chain(net.repr, 0, net.off_raw, net.init_pre, &net.n_init_pre);
+    heads({{&net.policy, net.off_norm, net.off_policy}, {&net.value, net.off_norm, net.off_value}}, net.init_post,
+          &net.n_init_post);
+    chain(net.dyn, 0, net.off_raw, net.rec_pre, &net.n_rec_pre);
+    heads({{&net.reward, net.off_raw, net.off_reward},
+           {&net.policy, net.off_norm, net.off_policy},
+           {&net.value, net.off_norm, net.off_value}},
+          net.rec_post, &net.n_rec_post);
     eng->fc = net;
     eng->fc_weights = weights;
     eng->fc_ready = true;

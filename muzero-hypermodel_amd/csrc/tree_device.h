@@ -20,28 +20,62 @@ namespace mz {
 
 constexpr int kStageLevels = 16;
 
+// ---- intra-group exchange ---------------------------------------------------------------------------
+// partner<M>(v): the value held by the lane this lane pairs with at butterfly step M.  Steps 1 and 2 are
+// quad permutes, 4 and 8 the half-row / row mirrors -- all DPP modifiers, i.e. plain VALU moves with no
+// trip through the LDS crossbar (a ds_bpermute costs an LDS round trip, ~100+ cycles on the dependent
+// chain of a one-wave-per-SIMD kernel); 16 and 32 fall back to ds_bpermute.  Mirrors pair every lane
+// with a lane of the opposite half, which is all a reduction of already half-uniform values needs.
+template <int M>
+__device__ __forceinline__ int partner_bits(int v) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+    else return __shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ float partner(float v) {
+    return __builtin_bit_cast(float, partner_bits<M>(__builtin_bit_cast(int, v)));
+}
+template <int M>
+__device__ __forceinline__ double partner(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = partner_bits<M>(static_cast<int>(bits & 0xffffffffll));
+    const int hi = partner_bits<M>(static_cast<int>(bits >> 32));
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+#define MZ_BUTTERFLY(G_, LIMIT_, EXPR)                                  \
+    do {                                                                \
+        if constexpr ((G_) >= 2) { if ((LIMIT_) >= 2) { constexpr int M = 1; EXPR; } }    \
+        if constexpr ((G_) >= 4) { if ((LIMIT_) >= 4) { constexpr int M = 2; EXPR; } }    \
+        if constexpr ((G_) >= 8) { if ((LIMIT_) >= 8) { constexpr int M = 4; EXPR; } }    \
+        if constexpr ((G_) >= 16) { if ((LIMIT_) >= 16) { constexpr int M = 8; EXPR; } }  \
+        if constexpr ((G_) >= 32) { if ((LIMIT_) >= 32) { constexpr int M = 16; EXPR; } } \
+        if constexpr ((G_) >= 64) { if ((LIMIT_) >= 64) { constexpr int M = 32; EXPR; } } \
+    } while (0)
+
+// max over the first `span` lanes of the group (span = pow2 <= G; lanes beyond it hold -inf and their
+// result is not used): the UCB arg-max only ever involves pow2(A) lanes however wide the group is.
 template <int G>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, G));
+__device__ __forceinline__ double group_max(double v, int span = G) {
+    MZ_BUTTERFLY(G, span, v = fmax(v, partner<M>(v)));
     return v;
 }
 template <int G>
 __device__ __forceinline__ float group_maxf(float v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, G));
+    MZ_BUTTERFLY(G, G, v = fmaxf(v, partner<M>(v)));
     return v;
 }
 template <int G>
 __device__ __forceinline__ float group_minf(float v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, G));
+    MZ_BUTTERFLY(G, G, v = fminf(v, partner<M>(v)));
     return v;
 }
 template <int G>
 __device__ __forceinline__ float group_sumf(float v) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) v = v + __shfl_xor(v, m, G);
+    MZ_BUTTERFLY(G, G, v = v + partner<M>(v));
     return v;
 }
 
@@ -123,6 +157,8 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
                                            uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j, int group_base,
                                            int32_t* path_ties /* this tree's column or null */, int ties_stride,
                                            int32_t* error_flag) {
+    int span = 1;  // lanes that can hold a child: pow2 >= min(A, G)
+    while (span < A && span < G) span <<= 1;
     int n_children = n_root_children;
     int k = 0;    // expanded-node index of the current parent
     int N = sim;  // its visit count: the root has been visited once per finished simulation
@@ -149,7 +185,7 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
                 best = fmax(best, score[c]);
             }
         }
-        best = group_max<G>(best);
+        best = group_max<G>(best, span);
 
         // tie list in child order (self_play.py:372-378)
         unsigned long long tie_mask[CH];
@@ -207,20 +243,8 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
     return Descent{depth, k, slot};
 }
 
-// models.py:641-662 support_to_scalar, fp32, torch's operation order; the F logits of one tree are
-// spread over the G lanes of its group.
-template <int G>
-__device__ __forceinline__ float support_to_scalar_group(const float* logits, int F, int support, int j) {
-    float m = -INFINITY;
-    for (int i = j; i < F; i += G) m = fmaxf(m, logits[i]);
-    m = group_maxf<G>(m);
-    float s = 0.f;
-    for (int i = j; i < F; i += G) s += expf(logits[i] - m);
-    s = group_sumf<G>(s);
-    const float inv = 1.0f / s;
-    float acc = 0.f;
-    for (int i = j; i < F; i += G) acc += static_cast<float>(i - support) * (expf(logits[i] - m) * inv);
-    const float x = group_sumf<G>(acc);
+// models.py:656-661: invert the value scaling, fp32, torch's operation order.
+__device__ __forceinline__ float inverse_value_transform(float x) {
     const float u = (fabsf(x) + 1.0f) + 0.001f;
     const float w = 0.004f * u;
     const float r = sqrtf(1.0f + w) - 1.0f;
@@ -228,6 +252,83 @@ __device__ __forceinline__ float support_to_scalar_group(const float* logits, in
     const float y = q * q - 1.0f;
     const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
     return sgn * y;
+}
+
+// models.py:641-662 support_to_scalar for TWO logit vectors at once (value and reward), fp32, torch's
+// operation order per vector; the two reductions are interleaved so their dependent chains overlap.
+// The F logits of a vector are spread over the G lanes of the group; with at most 4 per lane the
+// exponentials are computed once and kept in registers.  A vector's result does not depend on the other.
+template <int G>
+__device__ __forceinline__ void support_to_scalar_pair(const float* la, const float* lb, int F, int support, int j,
+                                                       float& out_a, float& out_b) {
+    const bool small = F <= 4 * G;
+    float xa[4], xb[4], ea[4], eb[4];
+    float ma = -INFINITY, mb = -INFINITY;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = j + u * G;
+            xa[u] = (i < F) ? la[i] : -INFINITY;
+            xb[u] = (i < F) ? lb[i] : -INFINITY;
+            ma = fmaxf(ma, xa[u]);
+            mb = fmaxf(mb, xb[u]);
+        }
+    } else {
+        for (int i = j; i < F; i += G) {
+            ma = fmaxf(ma, la[i]);
+            mb = fmaxf(mb, lb[i]);
+        }
+    }
+    MZ_BUTTERFLY(G, G, (ma = fmaxf(ma, partner<M>(ma)), mb = fmaxf(mb, partner<M>(mb))));
+    float sa = 0.f, sb = 0.f;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = j + u * G;
+            ea[u] = (i < F) ? expf(xa[u] - ma) : 0.f;
+            eb[u] = (i < F) ? expf(xb[u] - mb) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // same accumulation order as the strided loop: j, j+G, j+2G, ...
+            if (j + u * G < F) {
+                sa += ea[u];
+                sb += eb[u];
+            }
+        }
+    } else {
+        for (int i = j; i < F; i += G) {
+            sa += expf(la[i] - ma);
+            sb += expf(lb[i] - mb);
+        }
+    }
+    MZ_BUTTERFLY(G, G, (sa = sa + partner<M>(sa), sb = sb + partner<M>(sb)));
+    const float inva = 1.0f / sa, invb = 1.0f / sb;
+    float acca = 0.f, accb = 0.f;
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = j + u * G;
+            if (i < F) {
+                acca += static_cast<float>(i - support) * (ea[u] * inva);
+                accb += static_cast<float>(i - support) * (eb[u] * invb);
+            }
+        }
+    } else {
+        for (int i = j; i < F; i += G) {
+            acca += static_cast<float>(i - support) * (expf(la[i] - ma) * inva);
+            accb += static_cast<float>(i - support) * (expf(lb[i] - mb) * invb);
+        }
+    }
+    MZ_BUTTERFLY(G, G, (acca = acca + partner<M>(acca), accb = accb + partner<M>(accb)));
+    out_a = inverse_value_transform(acca);
+    out_b = inverse_value_transform(accb);
+}
+
+template <int G>
+__device__ __forceinline__ float support_to_scalar_group(const float* logits, int F, int support, int j) {
+    float a, b;
+    support_to_scalar_pair<G>(logits, logits, F, support, j, a, b);
+    return a;
 }
 
 // fp32 softmax over the children of one group (Node.expand, self_play.py:461-463): max, exp,

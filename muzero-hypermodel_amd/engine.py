@@ -65,6 +65,7 @@ class BatchedMCTS:
         self._graph_model = None
         self._profiling = False
         self._group_width = int(group_width)
+        self.stream = None          # optional dedicated torch.cuda.Stream (PipelinedSearch)
         self._fc_model = None
         self._fc_flat = None
         self.fused_hidden_in_lds = True
@@ -102,6 +103,13 @@ class BatchedMCTS:
             root_visits=np.zeros(E, np.int32), max_tree_depth=np.zeros(E, np.int32),
             root_predicted_value=np.zeros(E), min_max=np.zeros((E, 2)),
             depth_sum=np.zeros(E, np.int64), tie_break_words=np.zeros(E, np.uint32))
+        # ctypes pointers of the persistent host buffers (ndarray.ctypes is slow: build them once)
+        self._p_legal, self._p_nlegal = ptr(self._legal, c_i32_p), ptr(self._nlegal, c_i32_p)
+        self._p_to_play, self._p_noise = ptr(self._to_play, c_i32_p), ptr(self.noise, c_f64_p)
+        self._actions = np.zeros(E, np.int32)
+        self._slots = np.zeros(E, np.int32)
+        self._p_actions, self._p_slots = ptr(self._actions, c_i32_p), ptr(self._slots, c_i32_p)
+        self._temp_cache = (None, None)
         s = self.stats
         self._stats_struct = MzRootStats(
             ptr(s["visits"], c_i32_p), ptr(s["child_value_sum"], c_f64_p), ptr(s["child_prior"], c_f64_p),
@@ -127,7 +135,8 @@ class BatchedMCTS:
         _native.check(self._lib, self._h, rc)
 
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(stream.cuda_stream)
 
     # ---- RNG ------------------------------------------------------------------------------------
     def seed(self, seeds):
@@ -164,10 +173,10 @@ class BatchedMCTS:
                 self._nlegal[e] = n
                 if n:
                     self._legal[e, :n] = legal
-        self._to_play[:] = np.asarray(to_play, dtype=np.int32)
+        self._to_play[:] = to_play
         self._check(self._lib.mzmcts_begin_search(
-            self._h, ptr(self._legal, c_i32_p), ptr(self._nlegal, c_i32_p), ptr(self._to_play, c_i32_p),
-            1 if add_exploration_noise else 0, ptr(self.noise, c_f64_p), self._stream()))
+            self._h, self._p_legal, self._p_nlegal, self._p_to_play,
+            1 if add_exploration_noise else 0, self._p_noise, self._stream()))
 
     def expand_roots(self, value_logits, reward_logits, policy_logits, root_hidden=None):
         v, p = self._f32(value_logits, self.F), self._f32(policy_logits, self.A)
@@ -298,6 +307,7 @@ class BatchedMCTS:
                 desc.hidden[i][k] = int(width)
         self._check(self._lib.mzmcts_fc_configure(self._h, ctypes.byref(desc), flat.flat.data_ptr(), flat.numel))
         self._fc_model, self._fc_flat = model, flat
+        self._fc_obs_floats = int(desc.observation_floats)
         self._fc_out = (torch.empty((self.E, self.F), dtype=torch.float32, device=self.device),
                         torch.empty((self.E, self.F), dtype=torch.float32, device=self.device),
                         torch.empty((self.E, self.A), dtype=torch.float32, device=self.device))
@@ -353,14 +363,28 @@ class BatchedMCTS:
 
     def search_fused(self, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
         """MCTS.run for all envs in ONE kernel launch (after configure_fused_fc)."""
-        obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
-        obs = obs.to(self.device, dtype=torch.float32).reshape(self.E, -1).contiguous()
+        if (torch.is_tensor(observations) and observations.is_cuda and observations.dtype == torch.float32
+                and observations.is_contiguous()):
+            obs = observations                      # already resident: no copies, no reshapes
+        else:
+            obs = torch.as_tensor(np.asarray(observations) if not torch.is_tensor(observations) else observations)
+            obs = obs.to(self.device, dtype=torch.float32).reshape(self.E, -1).contiguous()
+        assert obs.numel() == self.E * self._fc_obs_floats, "observation batch has the wrong size"
         with torch.cuda.device(self.device):
             self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
             self._keep = (obs,)
             self._check(self._lib.mzmcts_search_fused_fc(self._h, obs.data_ptr(),
                                                          1 if self.fused_hidden_in_lds else 0, self._stream()))
             return self.readout()
+
+    def search_fused_begin(self, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
+        """Asynchronous form of search_fused: queue upload, kernel and download on this engine's stream and
+        return; `readout()` later waits for them.  `observations` must be a resident fp32 CUDA tensor."""
+        self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
+        self._keep = (observations,)
+        self._check(self._lib.mzmcts_search_fused_fc(self._h, observations.data_ptr(),
+                                                     1 if self.fused_hidden_in_lds else 0, self._stream()))
+        self._check(self._lib.mzmcts_readout_begin(self._h, self._stream()))
 
     @torch.no_grad()
     def search(self, model, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
@@ -382,12 +406,18 @@ class BatchedMCTS:
 
     def sample_actions(self, temperature):
         """SelfPlay.select_action per env on its own RNG stream; returns (actions, slots)."""
-        t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
-        actions = np.zeros(self.E, np.int32)
-        slots = np.zeros(self.E, np.int32)
-        self._check(self._lib.mzmcts_sample_actions(self._h, ptr(t, c_f64_p), ptr(actions, c_i32_p),
-                                                    ptr(slots, c_i32_p)))
-        return actions, slots
+        if temperature is self._temp_cache[0]:
+            p_t = self._temp_cache[1]            # same ndarray object as last call: reuse its pointer
+        else:
+            if isinstance(temperature, np.ndarray) and temperature.dtype == np.float64 \
+                    and temperature.shape == (self.E,) and temperature.flags["C_CONTIGUOUS"]:
+                t = temperature
+            else:
+                t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+            p_t = ptr(t, c_f64_p)
+            self._temp_cache = (temperature if t is temperature else None, p_t, t)
+        self._check(self._lib.mzmcts_sample_actions(self._h, p_t, self._p_actions, self._p_slots))
+        return self._actions.copy(), self._slots.copy()
 
     def search_statistics(self):
         """GameHistory.store_search_statistics targets: (child_visits [E,A], root_values [E])."""
@@ -416,3 +446,49 @@ class BatchedMCTS:
         select = mean_depth * (8 + 24 * A) + 2 * 4 * H
         backup = (mean_depth + 1) * (28 + two) + 32 + 24 * A + 13 + 4 * (A + 2 * F)
         return dict(select=select, expand_backup=backup, total=select + backup)
+
+
+class PipelinedSearch:
+    """Several env groups of one GPU searched concurrently: group g = engine g on its own HIP stream.
+
+    The fused whole-move kernel is latency-bound per tree (its duration hardly depends on how many trees
+    a launch carries), and the host work of a move (Dirichlet draws, action sampling, unpacking) is
+    serial per group.  Splitting the E envs of a GPU into n groups and running them round-robin lets one
+    group's host work overlap the other groups' kernels:
+
+        for every group, in turn:  finish(g)  ->  host post/pre work  ->  begin(g) (async)
+
+    Env indices stay global: group g owns envs [g*E/n, (g+1)*E/n) with their global RNG seeds."""
+
+    def __init__(self, config, num_envs, model, flat, groups=4, device=None, seeds=None, group_width=0):
+        assert num_envs % groups == 0, "num_envs must divide evenly into groups"
+        self.E, self.groups, self.per_group = int(num_envs), int(groups), int(num_envs) // int(groups)
+        if seeds is None:
+            seeds = [int(config.seed) + e for e in range(self.E)]
+        self.engines = []
+        for g in range(self.groups):
+            lo, hi = g * self.per_group, (g + 1) * self.per_group
+            eng = BatchedMCTS(config, self.per_group, device=device, seeds=seeds[lo:hi], group_width=group_width)
+            eng.configure_fused_fc(model, flat)
+            eng.stream = torch.cuda.Stream(device=eng.device)
+            self.engines.append(eng)
+        self._in_flight = [False] * self.groups
+
+    def slice(self, g):
+        return slice(g * self.per_group, (g + 1) * self.per_group)
+
+    def begin(self, g, observations, legal, to_play, add_exploration_noise=True, num_legal=None):
+        """Queue group g's next search (observations: that group's resident [E/n, obs] tensor)."""
+        eng = self.engines[g]
+        eng.stream.wait_stream(torch.cuda.current_stream(eng.device))
+        eng.search_fused_begin(observations, legal, to_play, add_exploration_noise, num_legal)
+        self._in_flight[g] = True
+
+    def finish(self, g):
+        """Wait for group g's search; returns its stats dict (valid until its next begin)."""
+        self._in_flight[g] = False
+        return self.engines[g].readout()
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()
