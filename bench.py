@@ -61,7 +61,7 @@ def parse_args():
                          "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
-    ap.add_argument("--groups", type=int, default=4,
+    ap.add_argument("--groups", type=int, default=1,
                     help="fused mode: env groups per GPU searched concurrently on separate HIP streams")
     return ap.parse_args()
 
@@ -81,7 +81,7 @@ def main():
     w = load_golden("cartpole_weights")
     weights = {k: torch.from_numpy(w[k]) for k in w.files}
     fused = args.mode == "fused"
-    group = args.group if args.group else (4 if fused else 0)
+    group = args.group if args.group else (16 if fused else 0)
     actor = actor_mod.SearchActor(config, weights, E, rank=rank, device=device, use_graph=not args.no_graph,
                                   group_width=group, fused_fc=fused)
     engine, model = actor.engine, actor.model
@@ -101,7 +101,11 @@ def main():
         engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
         engine.sample_actions(temperature)
 
-    single_engine_step = one_step
+    def search_only_step(i):
+        """One move on the single full-size engine, no collectives (roofline leg, rank 0 only)."""
+        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
+        engine.sample_actions(temperature)
+
     pipe = None
     if fused and args.groups > 1:
         # n env groups on n streams: one group's host work overlaps the other groups' kernels
@@ -160,7 +164,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "cartpole_fc_4096envs_x_50sims", "envs_per_gpu": E, "simulations": S,
+        "config": {"workload": f"cartpole_fc_{E}envs_x_{S}sims", "envs_per_gpu": E, "simulations": S,
                    "actions": A,
                    "network": "fullyconnected (reference checkpoint), fp32 inference "
                               + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm"),
@@ -174,7 +178,7 @@ def main():
 
     if rank == 0:
         if args.profile_steps > 0:
-            result["roofline"], result["kernels"] = roofline_leg(engine, single_engine_step, args.profile_steps, device)
+            result["roofline"], result["kernels"] = roofline_leg(engine, search_only_step, args.profile_steps, device)
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline_leg(config, w, args.cpu_seconds)
             result["speedup_vs_reference_equivalent"] = value / result["cpu_baseline"]["reference_equivalent_value"]

@@ -22,6 +22,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MZ_REHEARSE_ON_ONE_GPU"):
+        # rehearsal of the N>1 code path on a one-GPU box: every rank shares cuda:0 and the process group
+        # runs over gloo (RCCL refuses two ranks on one device).  Never used for measurements.
+        backend, local_rank = "gloo", 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

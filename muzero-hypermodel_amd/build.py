@@ -13,10 +13,12 @@ LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
 SOURCES = ["mcts_kernels.hip", "mzmcts_capi.hip"]
 HEADERS = ["np_legacy_rng.h", "tree_layout.h", "tree_device.h", "fc_net_device.h", os.path.join("..", "..", "include", "mzmcts.h")]
 
+# -fno-slp-vectorize: packing adjacent scalar f32 FMAs into v_pk_fma_f32 costs more in register shuffles
+# than it saves in issue slots here (measured: fused kernel 595 -> 555 us).
 # -ffp-contract=off is part of the numerical contract: the fp64 UCB / backup arithmetic must not be
 # fused into FMAs or it stops being bit-identical to the reference's Python floats.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-variable"]
+               "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-variable"] + os.environ.get("MZMCTS_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

@@ -59,6 +59,8 @@ struct FcNet {
 // LDS plan of the fused whole-move kernel (bytes from the start of dynamic LDS).
 struct FusedLayout {
     uint32_t off_weights;
+    uint32_t off_table;    // NeuronDesc table
+    uint32_t off_rec_table;
     uint32_t off_trees;
     uint32_t tree_bytes;   // per-tree region
     uint32_t off_path;     // within a tree region
@@ -91,39 +93,72 @@ __device__ __forceinline__ void stage_fc_weights(const FcNet& net, const float* 
     stage_mlp_weights(net.value, flat, w_lds, tid, nthreads);
 }
 
-struct NeuronRef {
-    const float4* row;  // weight row (padded)
-    const float4* x;    // input vector (padded)
-    float* y;           // where the activation goes
+// ---- per-lane neuron descriptors ------------------------------------------------------------------
+// Which neurons a lane evaluates never changes during a kernel, so the (phase, neuron) -> (weight row,
+// input vector, output slot, bias, width) mapping is resolved ONCE per workgroup into an LDS table;
+// inside the simulation loop a lane fetches the four descriptors of a pass with four 16-byte reads
+// instead of re-deriving them from the kernel arguments (scalar loads + ~100 VALU ops per phase on the
+// dependent chain).  Entry n of a phase's table describes neuron n; a pass covers neurons
+// [pass*4G, (pass+1)*4G), lane j taking n = pass*4G + u*G + j for u = 0..3.
+struct alignas(16) NeuronDesc {
+    uint32_t row_bytes;  // weight row, byte offset from the on-chip weight copy
+    uint32_t xy;         // input offset | output offset << 16 (floats from the tree's scratch)
+    uint32_t meta;       // chunks (in_pad / 4) | elu << 8;  chunks == 0: no neuron
     float bias;
-    int chunks;         // in_pad / 4; 0 = no neuron
-    bool elu;
 };
 
-// Which job / row neuron n of a phase is.  The phase descriptor is a kernel argument (wave-uniform,
-// held in SGPRs); the job is picked with per-lane selects, never with a per-lane index into it (that
-// would turn every field access into a memory load from the kernarg segment).
-__device__ __forceinline__ NeuronRef locate_neuron(const FcPhase& ph, const float* w, float* scratch, int n) {
-    const bool live = n < ph.total_out;
-    const FcJob j0 = ph.job[0], j1 = ph.job[1], j2 = ph.job[2];
-    const bool past0 = ph.n_jobs > 1 && n >= j0.out;
-    const bool past1 = ph.n_jobs > 2 && n >= j0.out + j1.out;
-    int o = past1 ? n - j0.out - j1.out : (past0 ? n - j0.out : n);
-    const int in_pad = past1 ? j2.in_pad : (past0 ? j1.in_pad : j0.in_pad);
-    const int w_lds = past1 ? j2.w_lds : (past0 ? j1.w_lds : j0.w_lds);
-    const int b_lds = past1 ? j2.b_lds : (past0 ? j1.b_lds : j0.b_lds);
-    const int x_off = past1 ? j2.x_off : (past0 ? j1.x_off : j0.x_off);
-    const int y_off = past1 ? j2.y_off : (past0 ? j1.y_off : j0.y_off);
-    const int elu = past1 ? j2.elu : (past0 ? j1.elu : j0.elu);
-    o = live ? o : 0;  // a lane without a neuron still forms valid addresses (row 0) and never stores
-    NeuronRef r;
-    r.row = reinterpret_cast<const float4*>(w + w_lds + o * in_pad);
-    r.x = reinterpret_cast<const float4*>(scratch + x_off);
-    r.y = scratch + y_off + o;
-    r.bias = w[b_lds + o];
-    r.chunks = live ? (in_pad >> 2) : 0;
-    r.elu = elu != 0;
-    return r;
+__device__ __forceinline__ int phase_passes(const FcPhase& ph, int G) { return (ph.total_out + 4 * G - 1) / (4 * G); }
+
+__device__ __forceinline__ int phase_list_entries(const FcPhase* list, int n, int G) {
+    int total = 0;
+    for (int p = 0; p < n; ++p) total += phase_passes(list[p], G) * 4 * G;
+    return total;
+}
+
+// entries of all four phase lists, in the order init_pre, init_post, rec_pre, rec_post
+__device__ __forceinline__ int fc_table_entries(const FcNet& net, int G) {
+    return phase_list_entries(net.init_pre, net.n_init_pre, G) + phase_list_entries(net.init_post, net.n_init_post, G) +
+           phase_list_entries(net.rec_pre, net.n_rec_pre, G) + phase_list_entries(net.rec_post, net.n_rec_post, G);
+}
+
+__device__ __forceinline__ NeuronDesc describe_neuron(const FcPhase& ph, const float* w, int n) {
+    NeuronDesc d{0u, 0u, 0u, 0.f};
+    if (n >= ph.total_out) return d;
+    int jb = 0, o = n;
+    if (ph.n_jobs > 1 && o >= ph.job[0].out) {
+        o -= ph.job[0].out;
+        jb = 1;
+        if (ph.n_jobs > 2 && o >= ph.job[1].out) {
+            o -= ph.job[1].out;
+            jb = 2;
+        }
+    }
+    const FcJob J = ph.job[jb];
+    d.row_bytes = static_cast<uint32_t>(J.w_lds + o * J.in_pad) * 4u;
+    d.xy = static_cast<uint32_t>(J.x_off) | (static_cast<uint32_t>(J.y_off + o) << 16);
+    d.meta = static_cast<uint32_t>(J.in_pad >> 2) | (J.elu ? 0x100u : 0u);
+    d.bias = w[J.b_lds + o];
+    return d;
+}
+
+// Build the table of one phase list (all threads of the workgroup); returns entries written.
+__device__ __forceinline__ int build_phase_tables(const FcPhase* list, int n, const float* w, NeuronDesc* table, int G,
+                                                  int tid, int nthreads) {
+    int base = 0;
+    for (int p = 0; p < n; ++p) {
+        const int entries = phase_passes(list[p], G) * 4 * G;
+        for (int t = tid; t < entries; t += nthreads) table[base + t] = describe_neuron(list[p], w, t);
+        base += entries;
+    }
+    return base;
+}
+
+__device__ __forceinline__ void build_fc_tables(const FcNet& net, const float* w, NeuronDesc* table, int G, int tid,
+                                                int nthreads) {
+    int base = build_phase_tables(net.init_pre, net.n_init_pre, w, table, G, tid, nthreads);
+    base += build_phase_tables(net.init_post, net.n_init_post, w, table + base, G, tid, nthreads);
+    base += build_phase_tables(net.rec_pre, net.n_rec_pre, w, table + base, G, tid, nthreads);
+    build_phase_tables(net.rec_post, net.n_rec_post, w, table + base, G, tid, nthreads);
 }
 
 __device__ __forceinline__ float fma4(const float4& wv, const float4& xv, float acc) {
@@ -134,49 +169,89 @@ __device__ __forceinline__ float fma4(const float4& wv, const float4& xv, float 
     return acc;
 }
 
-__device__ __forceinline__ float elu_or_identity(float v, bool elu) {
-    const float e = expm1f(fminf(v, 0.f));  // ELU(alpha = 1) on the negative side
-    return (elu && !(v > 0.f)) ? e : v;
-}
+// ELU(alpha = 1) on the negative side: exp(v) - 1 (absolute error <= 1 ulp of 1, i.e. 6e-8, against the
+// reference's expm1 -- three orders below the 1e-5 bar -- at a third of expm1f's instruction count).
+__device__ __forceinline__ float elu_negative(float v) { return expf(fminf(v, 0.f)) - 1.0f; }
 
 // models.py:626-638, one phase: Linear (+ELU on hidden layers) for every neuron of up to three
 // independent layers.  Inputs must be visible to the group on entry; outputs are on exit.
-// Loads are unconditional (indices clamped into the row) so that they stay 16-byte LDS reads issued
-// back to back; chunks beyond a neuron's width are discarded with a select, not a branch.
+// Per pass a lane runs four neurons: their descriptors arrive with four 16-byte reads, then the loads
+// of two 4-input chunks per neuron (16 x 16-byte LDS reads) are issued back to back before the FMAs.
+// Loads are unconditional (indices clamped into the row); chunks beyond a neuron's width are dropped
+// with a select.  Each neuron is one sequential FMA chain over its inputs.
 template <int G>
-__device__ __forceinline__ void run_phase(const FcPhase& ph, const float* w, float* scratch, int j) {
-    constexpr int KB = 4;  // chunks (of 4 inputs) whose loads are issued together
-    for (int n0 = j; n0 < ph.total_out; n0 += 2 * G) {
-        const NeuronRef a = locate_neuron(ph, w, scratch, n0);
-        const NeuronRef b = locate_neuron(ph, w, scratch, n0 + G);
-        float acc_a = 0.f, acc_b = 0.f;
-        const int chunks = a.chunks > b.chunks ? a.chunks : b.chunks;
-        const int last_a = a.chunks > 0 ? a.chunks - 1 : 0, last_b = b.chunks > 0 ? b.chunks - 1 : 0;
-        for (int c0 = 0; c0 < chunks; c0 += KB) {
-            float4 wa[KB], xa[KB], wb[KB], xb[KB];
+__device__ __forceinline__ void run_phase(const FcPhase& ph, const NeuronDesc* table, const float* w, float* scratch,
+                                          int j) {
+    constexpr int KB = 2;  // chunks per neuron whose loads are issued together
+    const int passes = phase_passes(ph, G);
+    for (int pass = 0; pass < passes; ++pass) {
+        NeuronDesc d[4];
 #pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                const int ia = (c0 + u < last_a) ? c0 + u : last_a;
-                const int ib = (c0 + u < last_b) ? c0 + u : last_b;
-                wa[u] = a.row[ia];
-                xa[u] = a.x[ia];
-                wb[u] = b.row[ib];
-                xb[u] = b.x[ib];
+        for (int u = 0; u < 4; ++u) d[u] = table[pass * 4 * G + u * G + j];
+        const float4* row[4];
+        const float4* x[4];
+        int chunks[4], last[4];
+        float acc[4];
+        int max_chunks = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            row[u] = reinterpret_cast<const float4*>(reinterpret_cast<const uint8_t*>(w) + d[u].row_bytes);
+            x[u] = reinterpret_cast<const float4*>(scratch + (d[u].xy & 0xffffu));
+            chunks[u] = static_cast<int>(d[u].meta & 0xffu);
+            last[u] = chunks[u] > 0 ? chunks[u] - 1 : 0;
+            max_chunks = chunks[u] > max_chunks ? chunks[u] : max_chunks;
+            acc[u] = 0.f;
+        }
+        for (int c0 = 0; c0 < max_chunks; c0 += KB) {
+            float4 wv[4][KB], xv[4][KB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < KB; ++t) {
+                    const int i = (c0 + t < last[u]) ? c0 + t : last[u];
+                    wv[u][t] = row[u][i];
+                    xv[u][t] = x[u][i];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < KB; ++u) {
-                const float ta = fma4(wa[u], xa[u], acc_a);
-                const float tb = fma4(wb[u], xb[u], acc_b);
-                acc_a = (c0 + u < a.chunks) ? ta : acc_a;
-                acc_b = (c0 + u < b.chunks) ? tb : acc_b;
+            for (int t = 0; t < KB; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float next = fma4(wv[u][t], xv[u][t], acc[u]);
+                    acc[u] = (c0 + t < chunks[u]) ? next : acc[u];
+                }
             }
         }
-        const float va = elu_or_identity(acc_a + a.bias, a.elu);
-        const float vb = elu_or_identity(acc_b + b.bias, b.elu);
-        if (a.chunks) *a.y = va;
-        if (b.chunks) *b.y = vb;
+        float v[4];
+        bool any_elu = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = acc[u] + d[u].bias;
+            any_elu = any_elu || ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f));
+        }
+        if (__any(any_elu)) {  // hidden layers only: output layers never pay for the exponentials
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float e = elu_negative(v[u]);
+                v[u] = ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f)) ? e : v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (chunks[u]) scratch[d[u].xy >> 16] = v[u];
     }
     group_memory_fence();
+}
+
+// run a list of phases whose tables start at `table`; returns the table position after the list
+template <int G>
+__device__ __forceinline__ const NeuronDesc* run_phase_list(const FcPhase* list, int n, const NeuronDesc* table,
+                                                            const float* w, float* scratch, int j) {
+    for (int p = 0; p < n; ++p) {
+        run_phase<G>(list[p], table, w, scratch, j);
+        table += phase_passes(list[p], G) * 4 * G;
+    }
+    return table;
 }
 
 // Row-wise min-max rescale to [0,1] (models.py:137-145, 161-168): raw -> norm.
@@ -205,29 +280,30 @@ __device__ __forceinline__ void fc_clear_scratch(const FcNet& net, float* scratc
 // models.py:172-190 initial_inference (the reward head is the constant log(one_hot): decodes to 0).
 // On exit scratch holds norm (the root hidden state), value logits and policy logits.
 template <int G>
-__device__ __forceinline__ void fc_initial(const FcNet& net, const float* w, float* scratch, const float* obs, int j) {
+__device__ __forceinline__ void fc_initial(const FcNet& net, const NeuronDesc* table, const float* w, float* scratch,
+                                           const float* obs, int j) {
     float* x = scratch;
     for (int i = j; i < ((net.obs + 3) & ~3); i += G) x[i] = (i < net.obs) ? obs[i] : 0.f;
     group_memory_fence();
-    for (int ph = 0; ph < net.n_init_pre; ++ph) run_phase<G>(net.init_pre[ph], w, scratch, j);
+    table = run_phase_list<G>(net.init_pre, net.n_init_pre, table, w, scratch, j);
     unit_rescale<G>(scratch + net.off_raw, scratch + net.off_norm, net.enc, j);
-    for (int ph = 0; ph < net.n_init_post; ++ph) run_phase<G>(net.init_post[ph], w, scratch, j);
+    run_phase_list<G>(net.init_post, net.n_init_post, table, w, scratch, j);
 }
 
 // models.py:147-170, 192-195 recurrent_inference.  On exit scratch holds norm (next hidden state),
 // reward / value / policy logits.  The reward head reads the UN-normalised next state
 // (models.py:157-159), so all three heads can run side by side once the rescale is done.
 template <int G>
-__device__ __forceinline__ void fc_recurrent(const FcNet& net, const float* w, float* scratch, const float* hidden,
-                                             int action, int j) {
+__device__ __forceinline__ void fc_recurrent(const FcNet& net, const NeuronDesc* rec_table, const float* w, float* scratch,
+                                             const float* hidden, int action, int j) {
     float* x = scratch;
     for (int i = j; i < net.enc; i += G) x[i] = hidden[i];
     // one-hot action, then zeros up to the padded width
     for (int a = j; net.enc + a < ((net.enc + net.A + 3) & ~3); a += G) x[net.enc + a] = (a == action) ? 1.f : 0.f;
     group_memory_fence();
-    for (int ph = 0; ph < net.n_rec_pre; ++ph) run_phase<G>(net.rec_pre[ph], w, scratch, j);
+    rec_table = run_phase_list<G>(net.rec_pre, net.n_rec_pre, rec_table, w, scratch, j);
     unit_rescale<G>(scratch + net.off_raw, scratch + net.off_norm, net.enc, j);
-    for (int ph = 0; ph < net.n_rec_post; ++ph) run_phase<G>(net.rec_post[ph], w, scratch, j);
+    run_phase_list<G>(net.rec_post, net.n_rec_post, rec_table, w, scratch, j);
 }
 
 }  // namespace mz

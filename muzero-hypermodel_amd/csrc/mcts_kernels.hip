@@ -34,8 +34,8 @@ namespace mz {
 // Diagnostic build only (-DMZ_STAMPS, tools/stamp_fused.py): per-phase cycle sums of the fused kernel,
 // written to a debug buffer that nothing else reads.  The production library never defines it.
 #ifdef MZ_STAMPS
-__device__ unsigned long long g_stamp_sums[8];
-#define MZ_STAMP_DECL unsigned long long stamp_prev = __builtin_readcyclecounter(), stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_stamp_sums[16];
+#define MZ_STAMP_DECL unsigned long long stamp_prev = __builtin_readcyclecounter(), stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define MZ_STAMP(slot)                                                   \
     do {                                                                 \
         const unsigned long long now__ = __builtin_readcyclecounter();   \
@@ -45,7 +45,7 @@ __device__ unsigned long long g_stamp_sums[8];
 #define MZ_STAMP_FLUSH                                                                        \
     do {                                                                                      \
         if (threadIdx.x == 0)                                                                 \
-            for (int s__ = 0; s__ < 8; ++s__) atomicAdd(&g_stamp_sums[s__], stamp_acc[s__]);  \
+            for (int s__ = 0; s__ < 16; ++s__) atomicAdd(&g_stamp_sums[s__], stamp_acc[s__]);  \
     } while (0)
 #else
 #define MZ_STAMP_DECL
@@ -324,20 +324,27 @@ __global__ __launch_bounds__(kThreads) void fc_inference_kernel(FcNet net, const
     extern __shared__ __attribute__((aligned(16))) float fc_smem[];  // [padded weights][64/G][scratch_floats]
     constexpr int kTrees = kThreads / G;
     float* w_lds = fc_smem;
+    NeuronDesc* table = reinterpret_cast<NeuronDesc*>(fc_smem + ((net.n_weights_lds + 3) & ~3));
     stage_fc_weights(net, weights, w_lds, threadIdx.x, kThreads);
     __syncthreads();
+    build_fc_tables(net, w_lds, table, G, threadIdx.x, kThreads);
+    __syncthreads();
+    const int init_entries = phase_list_entries(net.init_pre, net.n_init_pre, G) +
+                             phase_list_entries(net.init_post, net.n_init_post, G);
     const int tree_in_block = threadIdx.x / G;
     const int e = blockIdx.x * kTrees + tree_in_block;
     const int j = threadIdx.x % G;
     if (e >= E) return;
-    float* scratch = fc_smem + ((net.n_weights_lds + 3) & ~3) + static_cast<size_t>(tree_in_block) * net.scratch_floats;
+    float* scratch = reinterpret_cast<float*>(table + fc_table_entries(net, G)) +
+                     static_cast<size_t>(tree_in_block) * net.scratch_floats;
     fc_clear_scratch<G>(net, scratch, j);
     if (INITIAL) {
-        fc_initial<G>(net, w_lds, scratch, in + static_cast<size_t>(e) * net.obs, j);
+        fc_initial<G>(net, table, w_lds, scratch, in + static_cast<size_t>(e) * net.obs, j);
         for (int i = j; i < net.F; i += G)
             reward_logits[static_cast<size_t>(e) * net.F + i] = (i == net.F / 2) ? 0.f : -INFINITY;
     } else {
-        fc_recurrent<G>(net, w_lds, scratch, in + static_cast<size_t>(e) * net.enc, static_cast<int>(action[e]), j);
+        fc_recurrent<G>(net, table + init_entries, w_lds, scratch, in + static_cast<size_t>(e) * net.enc,
+                        static_cast<int>(action[e]), j);
         for (int i = j; i < net.F; i += G) reward_logits[static_cast<size_t>(e) * net.F + i] = scratch[net.off_reward + i];
     }
     for (int i = j; i < net.F; i += G) value_logits[static_cast<size_t>(e) * net.F + i] = scratch[net.off_value + i];
@@ -365,8 +372,12 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
     MZ_STAMP_DECL
     double* pbc_table = reinterpret_cast<double*>(smem);
     float* w_lds = reinterpret_cast<float*>(smem + lay.off_weights);
+    const NeuronDesc* fc_table = reinterpret_cast<const NeuronDesc*>(smem + lay.off_table);
+    const NeuronDesc* rec_table = reinterpret_cast<const NeuronDesc*>(smem + lay.off_rec_table);
     stage_pbc_table(pbc_table, p);
     stage_fc_weights(net, weights, w_lds, threadIdx.x, kThreads);
+    __syncthreads();
+    build_fc_tables(net, w_lds, reinterpret_cast<NeuronDesc*>(smem + lay.off_table), G, threadIdx.x, kThreads);
     __syncthreads();
     MZ_STAMP(0);
 
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
 
     // ---- root: initial inference, root.expand over the legal actions, exploration noise ----------
     fc_clear_scratch<G>(net, scratch, j);
-    fc_initial<G>(net, w_lds, scratch, observations + static_cast<size_t>(e) * net.obs, j);
+    fc_initial<G>(net, fc_table, w_lds, scratch, observations + static_cast<size_t>(e) * net.obs, j);
     const float predicted = support_to_scalar_group<G>(scratch + net.off_value, net.F, net.support, j);
     {
         float logit[CH];
@@ -433,7 +444,30 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         const float* parent_hidden = hidden_in_lds
                                          ? hidden_lds + static_cast<size_t>(d.parent) * H
                                          : p.hidden + (static_cast<size_t>(d.parent) * p.E + e) * H;
-        fc_recurrent<G>(net, w_lds, scratch, parent_hidden, action, j);
+#ifdef MZ_STAMPS
+        {
+            float* x = scratch;
+            for (int i = j; i < net.enc; i += G) x[i] = parent_hidden[i];
+            for (int a = j; net.enc + a < ((net.enc + net.A + 3) & ~3); a += G) x[net.enc + a] = (a == action) ? 1.f : 0.f;
+            group_memory_fence();
+            MZ_STAMP(8);
+            const NeuronDesc* tb = rec_table;
+            for (int ph = 0; ph < net.n_rec_pre; ++ph) {
+                run_phase<G>(net.rec_pre[ph], tb, w_lds, scratch, j);
+                tb += phase_passes(net.rec_pre[ph], G) * 4 * G;
+                MZ_STAMP(9 + ph);
+            }
+            unit_rescale<G>(scratch + net.off_raw, scratch + net.off_norm, net.enc, j);
+            MZ_STAMP(12);
+            for (int ph = 0; ph < net.n_rec_post; ++ph) {
+                run_phase<G>(net.rec_post[ph], tb, w_lds, scratch, j);
+                tb += phase_passes(net.rec_post[ph], G) * 4 * G;
+                MZ_STAMP(13 + ph);
+            }
+        }
+#else
+        fc_recurrent<G>(net, rec_table, w_lds, scratch, parent_hidden, action, j);
+#endif
         MZ_STAMP(3);
         float value_f, reward_f;
         support_to_scalar_pair<G>(scratch + net.off_value, scratch + net.off_reward, net.F, net.support, j, value_f,
@@ -495,9 +529,9 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
 
 #ifdef MZ_STAMPS
 hipError_t read_stamp_sums(unsigned long long* out, bool reset) {
-    hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * 8);
+    hipError_t err = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * 16);
     if (err == hipSuccess && reset) {
-        unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long zeros[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         err = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sums), zeros, sizeof(zeros));
     }
     return err;
@@ -630,6 +664,19 @@ hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* see
     return hipGetLastError();
 }
 
+static int host_list_entries(const FcPhase* list, int n, int G) {
+    int total = 0;
+    for (int p = 0; p < n; ++p) total += (list[p].total_out + 4 * G - 1) / (4 * G) * 4 * G;
+    return total;
+}
+static int host_init_entries(const FcNet& net, int G) {
+    return host_list_entries(net.init_pre, net.n_init_pre, G) + host_list_entries(net.init_post, net.n_init_post, G);
+}
+static int host_table_entries(const FcNet& net, int G) {
+    return host_init_entries(net, G) + host_list_entries(net.rec_pre, net.n_rec_pre, G) +
+           host_list_entries(net.rec_post, net.n_rec_post, G);
+}
+
 hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const float* weights, bool initial, const float* in,
                                const int64_t* action, float* value_logits, float* reward_logits, float* policy_logits,
                                float* hidden_out, hipStream_t stream) {
@@ -637,7 +684,8 @@ hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const floa
     dispatch_group(p, [&](auto g, auto) {
         constexpr int G = decltype(g)::value;
         const size_t lds = sizeof(float) * (static_cast<size_t>((net.n_weights_lds + 3) & ~3) +
-                                            static_cast<size_t>(net.scratch_floats) * (kThreads / G));
+                                            static_cast<size_t>(net.scratch_floats) * (kThreads / G)) +
+                           sizeof(NeuronDesc) * static_cast<size_t>(host_table_entries(net, G));
         if (initial)
             fc_inference_kernel<G, true><<<dim3(grid), dim3(kThreads), lds, stream>>>(
                 net, weights, p.E, in, action, value_logits, reward_logits, policy_logits, hidden_out);
@@ -656,6 +704,9 @@ bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_i
     size_t off = align16(sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1));
     lay.off_weights = static_cast<uint32_t>(off);
     off = align16(off + sizeof(float) * static_cast<size_t>(net.n_weights_lds));
+    lay.off_table = static_cast<uint32_t>(off);
+    lay.off_rec_table = static_cast<uint32_t>(off + sizeof(NeuronDesc) * static_cast<size_t>(host_init_entries(net, p.group)));
+    off = align16(off + sizeof(NeuronDesc) * static_cast<size_t>(host_table_entries(net, p.group)));
     lay.off_trees = static_cast<uint32_t>(off);
     size_t t = static_cast<size_t>(p.S + 1) * p.block_stride;
     lay.off_path = static_cast<uint32_t>(t);

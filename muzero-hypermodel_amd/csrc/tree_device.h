@@ -194,7 +194,10 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
         for (int c = 0; c < CH; ++c) {
             const bool is_max = (c * G + j < n_children) && (score[c] == best);
             const unsigned long long ballot = __ballot(is_max);
-            tie_mask[c] = (G == 64) ? ballot : ((ballot >> group_base) & ((1ull << G) - 1ull));
+            if constexpr (G == 64)
+                tie_mask[c] = ballot;
+            else
+                tie_mask[c] = (ballot >> group_base) & ((1ull << G) - 1ull);
             n_ties += __popcll(tie_mask[c]);
         }
         int pick = 0;
@@ -218,8 +221,20 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
                     for (int i = 0; i < remaining; ++i) m &= m - 1ull;
                     const int bit = __ffsll(static_cast<long long>(m)) - 1;
                     slot = c * G + bit;
-                    sel_visits = __shfl(lk[c].visits, bit, G);
-                    sel_child = __shfl(lk[c].child_node, bit, G);
+                    // the chosen lane publishes its child's links to the group with an OR-butterfly of DPP
+                    // moves (child_node is biased by 1 so that "not expanded" (-1) contributes zero bits)
+                    int pub_visits = (j == bit) ? lk[c].visits : 0;
+                    int pub_child = (j == bit) ? lk[c].child_node + 1 : 0;
+                    if constexpr (G <= 16) {
+                        // over the whole group, so that every lane ends up with the values
+                        MZ_BUTTERFLY(G, G, (pub_visits |= partner_bits<M>(pub_visits),
+                                            pub_child |= partner_bits<M>(pub_child)));
+                    } else {
+                        pub_visits = __shfl(lk[c].visits, bit, G);
+                        pub_child = __shfl(lk[c].child_node, bit, G) + 1;
+                    }
+                    sel_visits = pub_visits;
+                    sel_child = pub_child - 1;
                     found = true;
                 } else if (!found) {
                     remaining -= cnt;  // (found / remaining are uniform across the group's lanes)

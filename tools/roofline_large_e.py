@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""HBM-scale run of the lock-step tree kernels ("a run with E scaled until node +
+hidden pools exceed 512 MB").  Injected network outputs (no inference), CartPole search constants
+(A=2, S=50, H=8), E trees; prints per-kernel mean duration (HIP events bound to the dispatch) and the
+achieved algorithmic GB/s against the 8 TB/s HBM roofline, as one JSON line.
+
+    python tools/roofline_large_e.py [log2_E=20] [A=2] [S=50] [H=8]
+"""
+import importlib, json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from parity_helpers import make_search_config
+
+log2e = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+A = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+E = 1 << log2e
+eng = importlib.import_module("muzero-hypermodel_amd.engine")
+cfg = make_search_config(A, S, 1 if A == 2 else 2, 0.997, H=H)
+t0 = time.time()
+engine = eng.BatchedMCTS(cfg, E)
+print(f"engine for E={E} built in {time.time()-t0:.1f}s, device pools {engine.device_bytes()/2**30:.2f} GiB", flush=True)
+g = torch.Generator(device="cuda").manual_seed(0)
+value = (torch.randn(E, generator=g, device="cuda", dtype=torch.float32) * 30).double()
+reward = torch.randn(E, generator=g, device="cuda", dtype=torch.float32).double()
+priors = torch.softmax(torch.randn(E, A, generator=g, device="cuda", dtype=torch.float32), dim=1).double()
+root_reward = torch.zeros(E, device="cuda", dtype=torch.float64)
+legal = np.tile(np.arange(A, dtype=np.int32), (E, 1)); nl = np.full(E, A, np.int32); tp = np.zeros(E, np.int32)
+lib, h = engine._lib, engine._h
+
+def move():
+    engine.begin_search(legal, tp, True, num_legal=nl)
+    engine._check(lib.mzmcts_expand_roots_injected(h, root_reward.data_ptr(), priors.data_ptr(), engine._stream()))
+    for s in range(S):
+        engine.select(gather=True)
+        engine._check(lib.mzmcts_expand_backup_injected(h, value.data_ptr(), reward.data_ptr(), priors.data_ptr(), engine._stream()))
+    return engine.readout()
+
+move()
+engine.set_profiling(True); engine.get_profile(reset=True)
+moves = 2
+for _ in range(moves):
+    st = move()
+torch.cuda.synchronize()
+prof = engine.get_profile(reset=True)
+d = prof["select_depth_sum"] / max(prof["simulations"], 1)
+b = engine.algorithmic_bytes_per_simulation(d)
+out = {"E": E, "A": A, "S": S, "H": H, "mean_select_depth": d, "device_pool_GiB": engine.device_bytes() / 2**30, "kernels": {}}
+for name, ms, n, per in (("select", "select_ms", "select_launches", b["select"]), ("expand_backup", "expand_backup_ms", "expand_backup_launches", b["expand_backup"])):
+    us = 1e3 * prof[ms] / prof[n]
+    out["kernels"][name] = {"avg_us": us, "launches": prof[n], "algorithmic_bytes_per_launch": per * E,
+                            "achieved_GBs": per * E / (us * 1e-6) / 1e9, "frac_of_8TBs": per * E / (us * 1e-6) / 8e12}
+out["tree_sims_per_s_kernels_only"] = E / ((out["kernels"]["select"]["avg_us"] + out["kernels"]["expand_backup"]["avg_us"]) * 1e-6)
+print(json.dumps(out))
+engine.close()

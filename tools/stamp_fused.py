@@ -26,7 +26,7 @@ def main():
     out_dir = os.path.join(ROOT, "tools", "_stamps")
     os.makedirs(out_dir, exist_ok=True)
     lib_path = os.path.join(out_dir, "libmzmcts.so")
-    cmd = [build._hipcc()] + build.HIPCC_FLAGS + ["-DMZ_STAMPS", "-o", lib_path] + build.SOURCES
+    cmd = [build._hipcc()] + build.HIPCC_FLAGS + ["-DMZ_STAMPS", "-fno-slp-vectorize", "-o", lib_path] + build.SOURCES
     subprocess.check_call(cmd, cwd=build.CSRC)
     build.LIB_PATH = lib_path
     native = importlib.import_module("muzero-hypermodel_amd._native")
@@ -44,7 +44,7 @@ def main():
     obs = torch.from_numpy(np.random.RandomState(0).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).cuda()
     legal = np.tile(np.arange(2, dtype=np.int32), (E, 1))
     nl = np.full(E, 2, np.int32)
-    sums = (ctypes.c_ulonglong * 8)()
+    sums = (ctypes.c_ulonglong * 16)()
     engine.search_fused(obs, legal, np.zeros(E, np.int32), True, num_legal=nl)
     lib.mzmcts_debug_read_stamps(sums, 1)
     moves = 5
@@ -53,7 +53,8 @@ def main():
     torch.cuda.synchronize()
     lib.mzmcts_debug_read_stamps(sums, 1)
     names = ["stage tables+weights", "root inference+expand", "descend", "fc_recurrent", "decode+softmax",
-             "write children+hidden", "backup", "publish"]
+             "write children+hidden", "backup", "publish", "  fc: stage x", "  fc: dynamics L1", "  fc: dynamics L2",
+             "  fc: (pre 3)", "  fc: rescale", "  fc: heads L1", "  fc: heads L2", "  fc: (post 3)"]
     trees_per_wg = 64 // group
     wgs = (E + trees_per_wg - 1) // trees_per_wg
     total = sum(sums)
