@@ -43,7 +43,9 @@ def test_resnet_matches_reference(models_mod, golden, name):
     fx = golden(f"g3_{name}_inference")
     model, _ = synthetic_model(models_mod, game_config(name))
     assert list(model.state_dict().keys()) == fx["state_dict_keys"].tolist()   # DataParallel-style keys
-    check_inference(model, fx, 2e-6)
+    # 1e-5: eval-mode batch norm is evaluated as the folded affine x*scale+shift (models.BatchNorm2d),
+    # which rounds differently from torch's (x-mean)*invstd*w+b in the last fp32 bits
+    check_inference(model, fx, 1e-5)
 
 
 def test_state_dict_keys_and_param_counts(models_mod, golden):
