@@ -100,6 +100,14 @@ class AbstractNetwork(torch.nn.Module):
 
     def set_weights(self, weights):
         self.load_state_dict(weights)
+        self.refresh_inference_constants()
+
+    def refresh_inference_constants(self):
+        """Recompute cached inference constants (folded batch-norm scale / shift) after the weights
+        changed behind the modules' backs, e.g. by a broadcast into aliased flat storage."""
+        for module in self.modules():
+            if isinstance(module, BatchNorm2d):
+                module.refold()
 
     def _zero_reward_logits(self, batch, device):
         # log(one_hot(centre)): -inf everywhere, 0 at the centre (reference models.py:176-183)
@@ -167,16 +175,49 @@ class MuZeroFullyConnectedNetwork(AbstractNetwork):
 # ------------------------------------------------------------------------------------------------
 class BatchNorm2d(torch.nn.BatchNorm2d):
     """torch.nn.BatchNorm2d (same parameters, buffers and state-dict keys) whose eval-mode forward is the
-    folded affine y = x * scale + shift in plain element-wise kernels.  On MI355X MIOpen's inference kernel
+    folded affine y = x * scale + shift: one element-wise kernel.  On MI355X MIOpen's inference kernel
     (`MIOpenBatchNormFwdInferSpatialEst`, also reached through torch.batch_norm) needs ~1 ms for a
-    [4096, 16, 3, 3] board batch -- 94 % of a TicTacToe simulation step -- where this form needs a few us."""
+    [4096, 16, 3, 3] board batch -- 94 % of a TicTacToe simulation step.
+
+    scale / shift are cached and refreshed IN PLACE (so a captured hipGraph keeps reading the same
+    addresses) whenever the parameters change: detected through their version counters, or signalled by
+    `refold()` after a weight broadcast into aliased storage (weights.FlatWeights)."""
+
+    def _fold_key(self):
+        return (self.weight._version, self.bias._version, self.running_mean._version,
+                self.running_var._version, self.weight.data_ptr(), self.weight.device)
+
+    def refold(self):
+        with torch.no_grad():
+            if getattr(self, "_scale", None) is None or self._scale.device != self.weight.device:
+                self._scale = torch.empty_like(self.weight)
+                self._shift = torch.empty_like(self.weight)
+            torch.mul(self.weight, torch.rsqrt(self.running_var + self.eps), out=self._scale)
+            torch.sub(self.bias, self.running_mean * self._scale, out=self._shift)
+        self._folded = self._fold_key()
 
     def forward(self, x):
         if self.training:
             return super().forward(x)
-        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
-        shift = self.bias - self.running_mean * scale
-        return torch.addcmul(shift.view(1, -1, 1, 1), x, scale.view(1, -1, 1, 1))
+        if getattr(self, "_folded", None) != self._fold_key():
+            self.refold()
+        return torch.addcmul(self._shift.view(1, -1, 1, 1), x, self._scale.view(1, -1, 1, 1))
+
+
+class PointwiseConv2d(torch.nn.Conv2d):
+    """1x1 convolution (same parameters / state-dict keys as torch.nn.Conv2d(c_in, c_out, 1)) evaluated as
+    ONE GEMM over all (sample, position) rows.  MIOpen lowers these tiny-board 1x1 convolutions to a
+    per-image im2col + GEMM loop (4096 launches per call at 4096 envs), which dominated a TicTacToe
+    simulation step."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, 1)
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+        out = torch.addmm(self.bias, rows, self.weight.view(self.out_channels, c).t())
+        return out.view(b, h, w, self.out_channels).permute(0, 3, 1, 2)
 
 
 def conv3x3(in_channels, out_channels, stride=1):
@@ -280,7 +321,7 @@ class DynamicsNetwork(torch.nn.Module):
         self.conv = conv3x3(num_channels, num_channels - 1)
         self.bn = BatchNorm2d(num_channels - 1)
         self.resblocks = _tower(num_channels - 1, num_blocks)
-        self.conv1x1_reward = torch.nn.Conv2d(num_channels - 1, reduced_channels_reward, 1)
+        self.conv1x1_reward = PointwiseConv2d(num_channels - 1, reduced_channels_reward)
         self.block_output_size_reward = block_output_size_reward
         self.fc = mlp(block_output_size_reward, fc_reward_layers, full_support_size)
 
@@ -298,8 +339,8 @@ class PredictionNetwork(torch.nn.Module):
                  block_output_size_value, block_output_size_policy):
         super().__init__()
         self.resblocks = _tower(num_channels, num_blocks)
-        self.conv1x1_value = torch.nn.Conv2d(num_channels, reduced_channels_value, 1)
-        self.conv1x1_policy = torch.nn.Conv2d(num_channels, reduced_channels_policy, 1)
+        self.conv1x1_value = PointwiseConv2d(num_channels, reduced_channels_value)
+        self.conv1x1_policy = PointwiseConv2d(num_channels, reduced_channels_policy)
         self.block_output_size_value = block_output_size_value
         self.block_output_size_policy = block_output_size_policy
         self.fc_value = mlp(block_output_size_value, fc_value_layers, full_support_size)

@@ -48,6 +48,8 @@ class FlatWeights:
             for k in self.float_keys:
                 src = torch.as_tensor(numpy.asarray(weights[k]) if not torch.is_tensor(weights[k]) else weights[k])
                 self.flat[self.offsets[k]: self.offsets[k] + src.numel()].copy_(src.reshape(-1))
+        if hasattr(self.model, "refresh_inference_constants"):
+            self.model.refresh_inference_constants()
 
     def state_dict(self):
         out = {k: self.flat[self.offsets[k]: self.offsets[k] + int(numpy.prod(self.shapes[k], dtype=numpy.int64))]
@@ -61,4 +63,7 @@ class FlatWeights:
         """Refresh every actor's weights from rank `src` (the trainer / shared-storage role)."""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return None
-        return dist.broadcast(self.flat, src=src, group=group, async_op=async_op)
+        work = dist.broadcast(self.flat, src=src, group=group, async_op=async_op)
+        if not async_op and hasattr(self.model, "refresh_inference_constants"):
+            self.model.refresh_inference_constants()   # folded batch-norm constants follow the new weights
+        return work
