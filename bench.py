@@ -61,7 +61,7 @@ def parse_args():
                          "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
-    ap.add_argument("--groups", type=int, default=1,
+    ap.add_argument("--groups", type=int, default=2,
                     help="fused mode: env groups per GPU searched concurrently on separate HIP streams")
     return ap.parse_args()
 

@@ -173,72 +173,87 @@ __device__ __forceinline__ float fma4(const float4& wv, const float4& xv, float 
 // reference's expm1 -- three orders below the 1e-5 bar -- at a third of expm1f's instruction count).
 __device__ __forceinline__ float elu_negative(float v) { return expf(fminf(v, 0.f)) - 1.0f; }
 
+// One pass of a phase for a lane: NS neurons (n = base + u*G + j, u < NS).  Their descriptors arrive with
+// NS 16-byte reads, then the loads of KB 4-input chunks per neuron are issued back to back before the FMAs.
+// Loads are unconditional (indices clamped into the row); chunks beyond a neuron's width are dropped with
+// a select.  Each neuron is one sequential FMA chain over its inputs.
+template <int G, int NS>
+__device__ __forceinline__ void run_pass(const NeuronDesc* table, const float* w, float* scratch, int j) {
+    constexpr int KB = NS <= 2 ? 4 : 2;  // chunks per neuron whose loads are in flight together
+    NeuronDesc d[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) d[u] = table[u * G + j];
+    const float4* row[NS];
+    const float4* x[NS];
+    int chunks[NS], last[NS];
+    float acc[NS];
+    int max_chunks = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        row[u] = reinterpret_cast<const float4*>(reinterpret_cast<const uint8_t*>(w) + d[u].row_bytes);
+        x[u] = reinterpret_cast<const float4*>(scratch + (d[u].xy & 0xffffu));
+        chunks[u] = static_cast<int>(d[u].meta & 0xffu);
+        last[u] = chunks[u] > 0 ? chunks[u] - 1 : 0;
+        max_chunks = chunks[u] > max_chunks ? chunks[u] : max_chunks;
+        acc[u] = 0.f;
+    }
+    for (int c0 = 0; c0 < max_chunks; c0 += KB) {
+        float4 wv[NS][KB], xv[NS][KB];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                const int i = (c0 + t < last[u]) ? c0 + t : last[u];
+                wv[u][t] = row[u][i];
+                xv[u][t] = x[u][i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KB; ++t) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const float next = fma4(wv[u][t], xv[u][t], acc[u]);
+                acc[u] = (c0 + t < chunks[u]) ? next : acc[u];
+            }
+        }
+    }
+    float v[NS];
+    bool any_elu = false;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        v[u] = acc[u] + d[u].bias;
+        any_elu = any_elu || ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f));
+    }
+    if (__any(any_elu)) {  // hidden layers only: output layers never pay for the exponentials
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const float e = elu_negative(v[u]);
+            v[u] = ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f)) ? e : v[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+        if (chunks[u]) scratch[d[u].xy >> 16] = v[u];
+}
+
 // models.py:626-638, one phase: Linear (+ELU on hidden layers) for every neuron of up to three
 // independent layers.  Inputs must be visible to the group on entry; outputs are on exit.
-// Per pass a lane runs four neurons: their descriptors arrive with four 16-byte reads, then the loads
-// of two 4-input chunks per neuron (16 x 16-byte LDS reads) are issued back to back before the FMAs.
-// Loads are unconditional (indices clamped into the row); chunks beyond a neuron's width are dropped
-// with a select.  Each neuron is one sequential FMA chain over its inputs.
+// A pass covers 4G neurons of the phase's table; the last pass only runs as many neuron slots per lane
+// as the phase still has (a wave-uniform count), so a 16-neuron layer on a 16-lane group costs one slot.
 template <int G>
 __device__ __forceinline__ void run_phase(const FcPhase& ph, const NeuronDesc* table, const float* w, float* scratch,
                                           int j) {
-    constexpr int KB = 2;  // chunks per neuron whose loads are issued together
     const int passes = phase_passes(ph, G);
     for (int pass = 0; pass < passes; ++pass) {
-        NeuronDesc d[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = table[pass * 4 * G + u * G + j];
-        const float4* row[4];
-        const float4* x[4];
-        int chunks[4], last[4];
-        float acc[4];
-        int max_chunks = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            row[u] = reinterpret_cast<const float4*>(reinterpret_cast<const uint8_t*>(w) + d[u].row_bytes);
-            x[u] = reinterpret_cast<const float4*>(scratch + (d[u].xy & 0xffffu));
-            chunks[u] = static_cast<int>(d[u].meta & 0xffu);
-            last[u] = chunks[u] > 0 ? chunks[u] - 1 : 0;
-            max_chunks = chunks[u] > max_chunks ? chunks[u] : max_chunks;
-            acc[u] = 0.f;
+        const NeuronDesc* t = table + pass * 4 * G;
+        const int remaining = ph.total_out - pass * 4 * G;
+        const int slots = remaining >= 4 * G ? 4 : (remaining + G - 1) / G;
+        switch (slots) {
+            case 1: run_pass<G, 1>(t, w, scratch, j); break;
+            case 2: run_pass<G, 2>(t, w, scratch, j); break;
+            case 3: run_pass<G, 3>(t, w, scratch, j); break;
+            default: run_pass<G, 4>(t, w, scratch, j); break;
         }
-        for (int c0 = 0; c0 < max_chunks; c0 += KB) {
-            float4 wv[4][KB], xv[4][KB];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int t = 0; t < KB; ++t) {
-                    const int i = (c0 + t < last[u]) ? c0 + t : last[u];
-                    wv[u][t] = row[u][i];
-                    xv[u][t] = x[u][i];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < KB; ++t) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float next = fma4(wv[u][t], xv[u][t], acc[u]);
-                    acc[u] = (c0 + t < chunks[u]) ? next : acc[u];
-                }
-            }
-        }
-        float v[4];
-        bool any_elu = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            v[u] = acc[u] + d[u].bias;
-            any_elu = any_elu || ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f));
-        }
-        if (__any(any_elu)) {  // hidden layers only: output layers never pay for the exponentials
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float e = elu_negative(v[u]);
-                v[u] = ((d[u].meta & 0x100u) != 0u && !(v[u] > 0.f)) ? e : v[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (chunks[u]) scratch[d[u].xy >> 16] = v[u];
     }
     group_memory_fence();
 }
