@@ -211,9 +211,19 @@ class MCTS:
         self.config = config
         self._engine = None
 
-    def _get_engine(self, device):
+    def _get_engine(self, device, model):
         if self._engine is None:
-            self._engine = BatchedMCTS(self.config, 1, device=device, seeds=[0])
+            self._engine = BatchedMCTS(self.config, 1, device=device, seeds=[0],
+                                       group_width=16 if len(self.config.action_space) <= 16 else 0)
+            self._engine_model = None
+        if self.config.network == "fullyconnected" and self._engine_model is not model:
+            # fully-connected networks run the whole search in one fused HIP launch; the model's parameters
+            # become views into one flat buffer (values unchanged, set_weights keeps working)
+            try:
+                self._engine.configure_fused_fc(model)
+            except (NotImplementedError, RuntimeError):
+                pass                                # shape outside the fused kernel's range: lock-step path
+            self._engine_model = model
         return self._engine
 
     def close(self):
@@ -234,7 +244,7 @@ class MCTS:
         assert legal_actions, f"Legal actions should not be an empty array. Got {legal_actions}."
         assert set(legal_actions).issubset(set(self.config.action_space)), (
             "Legal actions should be a subset of the action space.")
-        engine = self._get_engine(device)
+        engine = self._get_engine(device, model)
         engine.set_rng_state(0, numpy.random.get_state())
         obs = torch.tensor(numpy.asarray(observation)).float().unsqueeze(0)
         stats = engine.search(model, obs, [list(legal_actions)], [to_play], add_exploration_noise)
@@ -436,8 +446,15 @@ class BatchedSelfPlay:
         self.model.set_weights(initial_checkpoint["weights"])
         self.model.to(self.device)
         self.model.eval()
+        fused = config.network == "fullyconnected"
         self.engine = BatchedMCTS(config, self.E, device=self.device,
-                                  seeds=[seed + e for e in range(self.E)], use_graph=use_graph)
+                                  seeds=[seed + e for e in range(self.E)], use_graph=use_graph,
+                                  group_width=16 if fused and len(config.action_space) <= 16 else 0)
+        if fused:
+            try:
+                self.engine.configure_fused_fc(self.model)      # whole move in one HIP launch
+            except (NotImplementedError, RuntimeError):
+                pass
         self.histories = [None] * self.E
         self.observations = [None] * self.E
         self.moves_played = 0

@@ -474,3 +474,27 @@ def test_batched_self_play_matches_single_env_actor(eng, models_mod, pkg):
         # batch 1), so values agree to the ResNet tolerance while every integer statistic is identical
         np.testing.assert_allclose(finished[e].root_values, gh.root_values, rtol=RESNET_TOL["value_tol"],
                                    atol=RESNET_TOL["value_tol"])
+
+
+def test_batched_self_play_cartpole_fused(eng, models_mod, pkg):
+    """BatchedSelfPlay on the CartPole plugin: FC network => the fused kernel; envs restart when done."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    cp = games("cartpole")
+    config = cp.MuZeroConfig()
+    config.max_moves = 30
+    _, weights = cartpole_model_and_weights(models_mod, config, "cpu")
+    E = 64
+    done = []
+    actor = sp.BatchedSelfPlay({"weights": weights}, cp.Game, config, 0, E)
+    assert actor.engine._fc_model is actor.model            # fused path configured
+    for _ in range(35):
+        actor.step(1.0, None, on_game=lambda e, gh: done.append((e, gh)))
+    actor.close()
+    assert actor.moves_played == 35 * E and len(done) >= E   # every env finished at least one game
+    for e, gh in done[:8]:
+        n = len(gh.action_history)
+        assert 2 <= n <= config.max_moves + 1
+        assert len(gh.child_visits) == n - 1 == len(gh.root_values)
+        assert all(abs(sum(cv) - 1.0) < 1e-12 for cv in gh.child_visits)
+        assert np.asarray(gh.observation_history[0]).shape == config.observation_shape
+        assert set(gh.action_history[1:]) <= {0, 1} and all(r == 1.0 for r in gh.reward_history[1:])
