@@ -494,7 +494,9 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         }
         group_memory_fence();
         MZ_STAMP(5);
-        backup<G>(tree, d.depth, sim, value, reward_f, two_player, p.discount, mm, root_value_sum, root_reward, nullptr, j);
+        // the activation scratch is dead once the heads are decoded: it doubles as the backup's hand-over area
+        backup<G>(tree, d.depth, sim, value, reward_f, two_player, p.discount, mm, root_value_sum, root_reward,
+                  reinterpret_cast<StagedNode*>(scratch), j);
         group_memory_fence();
         // the leader owns the running min-max statistics; every lane scores its child with them
         mm.minimum = __shfl(mm.minimum, 0, G);

@@ -951,7 +951,7 @@ int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float
             temp[h][t] = off;
             off += pad4(max_hidden);
         }
-    net.scratch_floats = off;
+    net.scratch_floats = std::max(off, 64);  // >= 256 B: the fused kernel's backup borrows it (tree_device.h)
     auto job_of = [&](const mz::FcMlp& m, int l, int x_first, int y_last, int head) {
         mz::FcJob jb{};
         const mz::FcLayer& L = m.layer[l];

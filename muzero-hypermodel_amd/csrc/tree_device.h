@@ -438,19 +438,63 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
         value = (two_player ? -reward : reward) + discount * value;
     }
     if constexpr (Acc::kInLds) {
-        if (j == 0) {
-            for (int level = depth - 2; level >= 0; --level) {
+        // Tree in LDS: one lane per path level.  The lanes fetch their nodes' records together, the leader
+        // runs only the value recursion itself (a multiply-add per level on rewards handed over through
+        // `staged`), then every lane finishes its own node -- the fp64 division for the node's mean value
+        // runs in parallel across the levels -- and the min-max statistics are reduced over the group
+        // (max / min are exact under any association).  Same operations on the same operands as the
+        // sequential walk, so the results are bit-identical to it.
+        constexpr int C = G < kStageLevels ? G : kStageLevels;
+        float* r_buf = reinterpret_cast<float*>(staged);        // [C] rewards, leaf side first
+        double* v_buf = reinterpret_cast<double*>(staged) + 8;  // [C] value arriving at each node
+        for (int hi = depth - 2; hi >= 0; hi -= C) {
+            const int count = (hi + 1 < C) ? hi + 1 : C;
+            const bool mine = j < count;
+            const int level = hi - j;  // this lane's node sits at tree depth level + 1
+            ChildStats* st = nullptr;
+            ChildLinks* lk = nullptr;
+            double vs = 0.0;
+            ChildLinks l{0.f, 0, -1, 0};
+            if (mine) {
                 const int packed = acc.path_load(level);
                 const int slot = packed & 0xffff;
-                ChildStats* st = acc.stats(packed >> 16) + slot;
-                ChildLinks* lk = acc.links(packed >> 16) + slot;
-                double vs = st->value_sum;
-                int32_t visits = lk->visits;
+                st = acc.stats(packed >> 16) + slot;
+                lk = acc.links(packed >> 16) + slot;
+                vs = st->value_sum;
+                l = *lk;
+                r_buf[j] = l.reward;
+            }
+            group_memory_fence();
+            if (j == 0) {
+                for (int i = 0; i < count; ++i) {
+                    v_buf[i] = value;
+                    const double r = static_cast<double>(r_buf[i]);
+                    const bool same = ((depth - (hi - i + 1)) & 1) == 0;
+                    value = (two_player ? (same ? -r : r) : r) + discount * value;
+                }
+            }
+            group_memory_fence();
+            double seen_max = -INFINITY, seen_min = INFINITY;
+            if (mine) {
+                const double v = v_buf[j];
+                const double r = static_cast<double>(l.reward);
                 const bool same = ((depth - (level + 1)) & 1) == 0;
-                backup_step(vs, visits, static_cast<double>(lk->reward), two_player, same, discount, value, mm);
+                vs += (two_player && !same) ? -v : v;
+                const int32_t visits = l.visits + 1;
+                const double q = vs / static_cast<double>(visits);
+                const double seen = r + discount * (two_player ? -q : q);
                 st->value_sum = vs;
                 lk->visits = visits;
+                seen_max = seen;
+                seen_min = seen;
             }
+            MZ_BUTTERFLY(G, G, (seen_max = fmax(seen_max, partner<M>(seen_max)),
+                                seen_min = fmin(seen_min, partner<M>(seen_min))));
+            if (j == 0) {
+                mm.maximum = fmax(mm.maximum, seen_max);
+                mm.minimum = fmin(mm.minimum, seen_min);
+            }
+            group_memory_fence();
         }
     } else {
         for (int hi = depth - 2; hi >= 0; hi -= kStageLevels) {
