@@ -89,6 +89,14 @@ PROTOTYPES = {
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
+    # include/mzenv.h
+    "mzenv_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u32_p, ctypes.POINTER(c_void)]),
+    "mzenv_destroy": (None, [c_void]),
+    "mzenv_last_error": (ctypes.c_char_p, [c_void]),
+    "mzenv_shape": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p]),
+    "mzenv_reset": (ctypes.c_int, [c_void, c_void, c_void]),
+    "mzenv_step": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void]),
+    "mzenv_observe": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
     "mzmcts_rng_create": (c_void, [ctypes.c_uint32]),
     "mzmcts_rng_destroy": (None, [c_void]),
     "mzmcts_rng_reseed": (None, [c_void, ctypes.c_uint32]),

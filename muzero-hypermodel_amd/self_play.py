@@ -512,3 +512,110 @@ class BatchedSelfPlay:
         for g in self.games:
             g.close()
         self.engine.close()
+
+
+class DeviceSelfPlay:
+    """Self-play with device-resident environments (games.device.DeviceEnvs): search, env step and
+    observation all stay on the GPU; per move the host only draws the exploration noise, samples the
+    actions (both on the per-env numpy-compatible RNG streams) and files the move into per-env histories.
+
+    Env e plays the game the host plugin `Game(seed + e)` would play with reference worker `seed + e`'s RNG
+    stream -- the same games `BatchedSelfPlay` produces with host envs (tests/test_gpu_envs.py) -- without
+    E Python `game.step` calls per move.  Finished games are rebuilt as ordinary `GameHistory` objects and
+    handed to `on_game(env_index, GameHistory)`."""
+
+    def __init__(self, initial_checkpoint, game_name, config, seed, num_envs, device=None, use_graph=True):
+        from .games.device import DeviceEnvs
+        assert config.stacked_observations == 0, "device envs do not stack past observations yet"
+        self.config = config
+        self.E = int(num_envs)
+        self.device = torch.device(device if device is not None else "cuda")
+        torch.manual_seed(seed)
+        self.model = models.MuZeroNetwork(config)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.to(self.device)
+        self.model.eval()
+        seeds = [seed + e for e in range(self.E)]
+        self.envs = DeviceEnvs(game_name, self.E, seeds=seeds, device=self.device)
+        assert self.envs.A == len(config.action_space) and self.envs.observation_shape == tuple(config.observation_shape)
+        fused = config.network == "fullyconnected"
+        self.engine = BatchedMCTS(config, self.E, device=self.device, seeds=seeds, use_graph=use_graph,
+                                  group_width=16 if fused and len(config.action_space) <= 16 else 0)
+        if fused:
+            try:
+                self.engine.configure_fused_fc(self.model)
+            except (NotImplementedError, RuntimeError):
+                pass
+        self.moves_played = 0
+        self.games_finished = 0
+        self._moves = []                                   # per move: dict of [E, ...] host arrays
+        self._start = numpy.zeros(self.E, dtype=numpy.int64)   # move index at which env e's current game began
+        self._first = self._observe_host()                 # reset observation / to_play of the current games
+
+    def _observe_host(self):
+        obs, legal, num_legal, to_play = self.envs.observe()
+        return dict(obs=obs.cpu().numpy(), legal=legal.cpu().numpy(), num_legal=num_legal.cpu().numpy(),
+                    to_play=to_play.cpu().numpy(), obs_dev=obs)
+
+    def set_weights(self, weights):
+        self.model.set_weights(weights)
+
+    def step(self, temperature, temperature_threshold=None, on_game=None):
+        """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
+        cfg, E = self.config, self.E
+        cur = self._first if not self._moves or self._moves[-1]["next"] is None else self._moves[-1]["next"]
+        self.engine.search(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True, num_legal=cur["num_legal"])
+        game_len = len(self._moves) - self._start + 1      # len(action_history) of each env before this move
+        temps = numpy.where((temperature_threshold is None) | (game_len < (temperature_threshold or 0)) |
+                            (not temperature_threshold), float(temperature), 0.0).astype(numpy.float64)
+        actions, _ = self.engine.sample_actions(numpy.ascontiguousarray(temps))
+        child_visits, root_values = self.engine.search_statistics()
+        reward, done = self.envs.step(actions)
+        reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
+        nxt = self._observe_host()
+        self._moves.append(dict(action=actions, reward=reward, child_visits=child_visits, root_values=root_values,
+                                before=cur, next=nxt))
+        over = done | (game_len + 1 > cfg.max_moves)
+        if over.any():
+            for e in numpy.flatnonzero(over):
+                self.games_finished += 1
+                if on_game is not None:
+                    on_game(int(e), self._history_of(int(e)))
+            mask = torch.from_numpy(over.astype(numpy.uint8)).to(self.device)
+            self.envs.reset(mask)
+            fresh = self._observe_host()
+            # envs that restarted begin a new game at the NEXT move index with their reset observation
+            for key in ("obs", "legal", "num_legal", "to_play"):
+                nxt[key][over] = fresh[key][over]
+            nxt["obs_dev"] = fresh["obs_dev"]
+            self._start[over] = len(self._moves)
+        # drop moves no running game can still need
+        oldest = int(self._start.min())
+        if oldest > 0 and oldest >= len(self._moves) // 2:
+            self._moves = self._moves[oldest:]
+            self._start -= oldest
+        self.moves_played += E
+
+    def _history_of(self, e):
+        """GameHistory of env e's finished game, in the reference's layout (self_play.py:116-121, 176-182)."""
+        gh = GameHistory()
+        moves = self._moves[int(self._start[e]):]
+        first = moves[0]["before"]
+        gh.action_history.append(0)
+        gh.observation_history.append(first["obs"][e].copy())
+        gh.reward_history.append(0)
+        gh.to_play_history.append(int(first["to_play"][e]))
+        for m in moves:
+            n = int(m["before"]["num_legal"][e])
+            legal = set(int(a) for a in m["before"]["legal"][e][:n])
+            gh.child_visits.append([float(v) if a in legal else 0 for a, v in enumerate(m["child_visits"][e])])
+            gh.root_values.append(float(m["root_values"][e]))
+            gh.action_history.append(int(m["action"][e]))
+            gh.observation_history.append(m["next"]["obs"][e].copy())
+            gh.reward_history.append(float(m["reward"][e]))
+            gh.to_play_history.append(int(m["next"]["to_play"][e]))
+        return gh
+
+    def close(self):
+        self.envs.close()
+        self.engine.close()

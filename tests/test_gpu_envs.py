@@ -1,0 +1,106 @@
+"""Device-resident environments (include/mzenv.h) against the host Game plugins of this package, which
+are themselves pinned to the reference's envs (tests/test_host_logic.py, fixture G11)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from parity_helpers import cartpole_model_and_weights, synthetic_model
+
+pytestmark = pytest.mark.gpu
+
+
+def games(name):
+    return importlib.import_module(f"muzero-hypermodel_amd.games.{name}")
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    return importlib.import_module("muzero-hypermodel_amd.games.device")
+
+
+@pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole"])
+def test_device_envs_match_host_plugins(dev, name):
+    E = 96
+    mod = games(name)
+    envs = dev.DeviceEnvs(name, E, seeds=list(range(E)))
+    host = [mod.Game(e) for e in range(E)]
+    host_obs = [g.reset() for g in host]
+    rs = np.random.RandomState(5)
+    exact = name != "cartpole"      # cart-pole: device cos/sin vs glibc may differ in the last bit
+    for step in range(60):
+        obs, legal, nl, tp = (t.cpu().numpy() for t in envs.observe())
+        actions = np.zeros(E, np.int32)
+        for e, g in enumerate(host):
+            want = np.asarray(host_obs[e], dtype=np.float32)
+            if exact:
+                assert np.array_equal(obs[e], want), (step, e)
+            else:
+                np.testing.assert_allclose(obs[e], want, rtol=1e-6, atol=1e-7)
+            assert legal[e][: nl[e]].tolist() == list(g.legal_actions()) and tp[e] == g.to_play()
+            actions[e] = rs.choice(g.legal_actions())
+        reward, done = envs.step(actions)
+        reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
+        restart = np.zeros(E, np.uint8)
+        for e, g in enumerate(host):
+            o, r, d = g.step(int(actions[e]))
+            assert reward[e] == r and done[e] == bool(d), (step, e)
+            host_obs[e] = o
+            if d:
+                host_obs[e] = g.reset()
+                restart[e] = 1
+        if restart.any():
+            envs.reset(torch.from_numpy(restart).cuda())
+    envs.close()
+
+
+def test_device_self_play_equals_host_env_self_play(dev, pkg):
+    """Full loop: DeviceSelfPlay (envs on the GPU) plays the same games as BatchedSelfPlay (host plugins)."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    ttt = games("tictactoe")
+    config = ttt.MuZeroConfig()
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E, moves = 16, 14
+    out = {}
+    for kind in ("host", "device"):
+        games_done = {}
+        if kind == "host":
+            actor = sp.BatchedSelfPlay({"weights": weights}, ttt.Game, config, 0, E, use_graph=False)
+        else:
+            actor = sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, use_graph=False)
+        for _ in range(moves):
+            actor.step(1.0, None, on_game=lambda e, gh: games_done.setdefault(e, []).append(gh))
+        actor.close()
+        out[kind] = games_done
+    assert set(out["host"]) == set(out["device"]) and len(out["host"]) == E
+    for e in out["host"]:
+        assert len(out["host"][e]) == len(out["device"][e])
+        for a, b in zip(out["host"][e], out["device"][e]):
+            assert a.action_history == b.action_history and a.to_play_history == b.to_play_history
+            assert a.reward_history == b.reward_history
+            assert np.array_equal(np.array(a.child_visits, dtype=float), np.array(b.child_visits, dtype=float))
+            np.testing.assert_allclose(a.root_values, b.root_values, rtol=0, atol=0)
+            for oa, ob in zip(a.observation_history, b.observation_history):
+                assert np.array_equal(np.asarray(oa, dtype=np.float32), ob)
+
+
+def test_device_self_play_cartpole_fused(dev, pkg):
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("cartpole").MuZeroConfig()
+    config.max_moves = 40
+    _, weights = cartpole_model_and_weights(models_mod, config, "cpu")
+    finished = []
+    actor = sp.DeviceSelfPlay({"weights": weights}, "cartpole", config, 0, 256)
+    assert actor.engine._fc_model is actor.model
+    for _ in range(45):
+        actor.step(1.0, None, on_game=lambda e, gh: finished.append(gh))
+    actor.close()
+    assert len(finished) >= 256
+    for gh in finished[:16]:
+        n = len(gh.action_history)
+        assert 2 <= n <= config.max_moves + 1 and len(gh.child_visits) == n - 1 == len(gh.root_values)
+        assert all(abs(sum(cv) - 1.0) < 1e-12 for cv in gh.child_visits)

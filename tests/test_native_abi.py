@@ -18,9 +18,12 @@ def native(pkg):
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mzmcts.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mzmcts_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("mzmcts.h", "mzenv.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mz(?:mcts|env)_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(native):
