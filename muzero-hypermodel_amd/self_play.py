@@ -514,32 +514,67 @@ class BatchedSelfPlay:
         self.engine.close()
 
 
+class PackedGames:
+    """A batch of finished games as arrays (what a device-side replay buffer would ingest directly).
+
+    Game i has `length[i]` moves; row layouts follow GameHistory (reference self_play.py:116-121, 176-182):
+      observations[i, 0..length]   observation_history (index 0 = reset observation)
+      actions[i, 0..length]        action_history      (index 0 = the reference's dummy action 0)
+      rewards[i, 0..length]        reward_history      (index 0 = 0)
+      to_play[i, 0..length]        to_play_history
+      child_visits[i, 0..length-1] visit-count targets, root_values[i, 0..length-1]
+    Entries past a game's length are padding."""
+
+    __slots__ = ("env_index", "length", "observations", "actions", "rewards", "to_play", "child_visits", "root_values")
+
+    def __init__(self, **arrays):
+        for k, v in arrays.items():
+            setattr(self, k, v)
+
+    def __len__(self):
+        return len(self.env_index)
+
+    def history(self, i):
+        """Game i as a reference-shaped GameHistory (Python lists)."""
+        n = int(self.length[i])
+        gh = GameHistory()
+        gh.observation_history = [o for o in self.observations[i, : n + 1]]
+        gh.action_history = self.actions[i, : n + 1].tolist()
+        gh.reward_history = self.rewards[i, : n + 1].tolist()
+        gh.to_play_history = self.to_play[i, : n + 1].tolist()
+        gh.child_visits = self.child_visits[i, :n].tolist()
+        gh.root_values = self.root_values[i, :n].tolist()
+        return gh
+
+
 class DeviceSelfPlay:
     """Self-play with device-resident environments (games.device.DeviceEnvs): search, env step and
     observation all stay on the GPU; per move the host only draws the exploration noise, samples the
-    actions (both on the per-env numpy-compatible RNG streams) and files the move into per-env histories.
+    actions (both on the per-env numpy-compatible RNG streams) and files the move into packed per-env
+    history rows.
 
     Env e plays the game the host plugin `Game(seed + e)` would play with reference worker `seed + e`'s RNG
     stream -- the same games `BatchedSelfPlay` produces with host envs (tests/test_gpu_envs.py) -- without
-    E Python `game.step` calls per move.  Finished games are rebuilt as ordinary `GameHistory` objects and
-    handed to `on_game(env_index, GameHistory)`."""
+    E Python `game.step` calls per move.  Finished games leave as one `PackedGames` batch per move through
+    `on_games(batch)`; `on_game(env_index, GameHistory)` is the per-game compatibility callback (it rebuilds
+    Python lists, which costs more than the search itself at thousands of envs)."""
 
     def __init__(self, initial_checkpoint, game_name, config, seed, num_envs, device=None, use_graph=True):
         from .games.device import DeviceEnvs
         assert config.stacked_observations == 0, "device envs do not stack past observations yet"
         self.config = config
-        self.E = int(num_envs)
+        self.E = E = int(num_envs)
         self.device = torch.device(device if device is not None else "cuda")
         torch.manual_seed(seed)
         self.model = models.MuZeroNetwork(config)
         self.model.set_weights(initial_checkpoint["weights"])
         self.model.to(self.device)
         self.model.eval()
-        seeds = [seed + e for e in range(self.E)]
-        self.envs = DeviceEnvs(game_name, self.E, seeds=seeds, device=self.device)
+        seeds = [seed + e for e in range(E)]
+        self.envs = DeviceEnvs(game_name, E, seeds=seeds, device=self.device)
         assert self.envs.A == len(config.action_space) and self.envs.observation_shape == tuple(config.observation_shape)
         fused = config.network == "fullyconnected"
-        self.engine = BatchedMCTS(config, self.E, device=self.device, seeds=seeds, use_graph=use_graph,
+        self.engine = BatchedMCTS(config, E, device=self.device, seeds=seeds, use_graph=use_graph,
                                   group_width=16 if fused and len(config.action_space) <= 16 else 0)
         if fused:
             try:
@@ -548,9 +583,19 @@ class DeviceSelfPlay:
                 pass
         self.moves_played = 0
         self.games_finished = 0
-        self._moves = []                                   # per move: dict of [E, ...] host arrays
-        self._start = numpy.zeros(self.E, dtype=numpy.int64)   # move index at which env e's current game began
-        self._first = self._observe_host()                 # reset observation / to_play of the current games
+        # packed history rows, one per env; every game starts at column 0 of its row
+        T, A = int(config.max_moves) + 1, self.envs.A
+        self._obs = numpy.zeros((E, T + 1) + self.envs.observation_shape, dtype=numpy.float32)
+        self._act = numpy.zeros((E, T + 1), dtype=numpy.int32)
+        self._rew = numpy.zeros((E, T + 1), dtype=numpy.float32)
+        self._tp = numpy.zeros((E, T + 1), dtype=numpy.int8)
+        self._cv = numpy.zeros((E, T, A), dtype=numpy.float64)
+        self._rv = numpy.zeros((E, T), dtype=numpy.float64)
+        self._len = numpy.zeros(E, dtype=numpy.int64)      # moves played in env e's current game
+        self._rows = numpy.arange(E)
+        self._cur = self._observe_host()
+        self._obs[:, 0] = self._cur["obs"]
+        self._tp[:, 0] = self._cur["to_play"]
 
     def _observe_host(self):
         obs, legal, num_legal, to_play = self.envs.observe()
@@ -560,61 +605,52 @@ class DeviceSelfPlay:
     def set_weights(self, weights):
         self.model.set_weights(weights)
 
-    def step(self, temperature, temperature_threshold=None, on_game=None):
+    def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
         """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
-        cfg, E = self.config, self.E
-        cur = self._first if not self._moves or self._moves[-1]["next"] is None else self._moves[-1]["next"]
+        cfg, cur, rows = self.config, self._cur, self._rows
         self.engine.search(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True, num_legal=cur["num_legal"])
-        game_len = len(self._moves) - self._start + 1      # len(action_history) of each env before this move
-        temps = numpy.where((temperature_threshold is None) | (game_len < (temperature_threshold or 0)) |
-                            (not temperature_threshold), float(temperature), 0.0).astype(numpy.float64)
-        actions, _ = self.engine.sample_actions(numpy.ascontiguousarray(temps))
+        if temperature_threshold:
+            # play_game: temperature only while len(action_history) < threshold (self_play.py:163-170)
+            temps = numpy.where(self._len + 1 < temperature_threshold, float(temperature), 0.0)
+        else:
+            temps = numpy.full(self.E, float(temperature))
+        actions, _ = self.engine.sample_actions(numpy.ascontiguousarray(temps, dtype=numpy.float64))
         child_visits, root_values = self.engine.search_statistics()
         reward, done = self.envs.step(actions)
-        reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
         nxt = self._observe_host()
-        self._moves.append(dict(action=actions, reward=reward, child_visits=child_visits, root_values=root_values,
-                                before=cur, next=nxt))
-        over = done | (game_len + 1 > cfg.max_moves)
+        reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
+        at = self._len
+        self._cv[rows, at] = child_visits
+        self._rv[rows, at] = root_values
+        self._act[rows, at + 1] = actions
+        self._rew[rows, at + 1] = reward
+        self._obs[rows, at + 1] = nxt["obs"]
+        self._tp[rows, at + 1] = nxt["to_play"]
+        self._len = at + 1
+        over = done | (self._len + 1 > cfg.max_moves)      # len(action_history) > max_moves ends the game
         if over.any():
-            for e in numpy.flatnonzero(over):
-                self.games_finished += 1
-                if on_game is not None:
-                    on_game(int(e), self._history_of(int(e)))
-            mask = torch.from_numpy(over.astype(numpy.uint8)).to(self.device)
-            self.envs.reset(mask)
+            idx = numpy.flatnonzero(over)
+            n = self._len[idx]
+            L = int(n.max())
+            batch = PackedGames(env_index=idx, length=n, observations=self._obs[idx, : L + 1],
+                                actions=self._act[idx, : L + 1], rewards=self._rew[idx, : L + 1],
+                                to_play=self._tp[idx, : L + 1], child_visits=self._cv[idx, :L], root_values=self._rv[idx, :L])
+            self.games_finished += len(idx)
+            if on_games is not None:
+                on_games(batch)
+            if on_game is not None:
+                for i, e in enumerate(idx):
+                    on_game(int(e), batch.history(i))
+            self.envs.reset(torch.from_numpy(over.astype(numpy.uint8)).to(self.device))
             fresh = self._observe_host()
-            # envs that restarted begin a new game at the NEXT move index with their reset observation
             for key in ("obs", "legal", "num_legal", "to_play"):
-                nxt[key][over] = fresh[key][over]
+                nxt[key][idx] = fresh[key][idx]
             nxt["obs_dev"] = fresh["obs_dev"]
-            self._start[over] = len(self._moves)
-        # drop moves no running game can still need
-        oldest = int(self._start.min())
-        if oldest > 0 and oldest >= len(self._moves) // 2:
-            self._moves = self._moves[oldest:]
-            self._start -= oldest
-        self.moves_played += E
-
-    def _history_of(self, e):
-        """GameHistory of env e's finished game, in the reference's layout (self_play.py:116-121, 176-182)."""
-        gh = GameHistory()
-        moves = self._moves[int(self._start[e]):]
-        first = moves[0]["before"]
-        gh.action_history.append(0)
-        gh.observation_history.append(first["obs"][e].copy())
-        gh.reward_history.append(0)
-        gh.to_play_history.append(int(first["to_play"][e]))
-        for m in moves:
-            n = int(m["before"]["num_legal"][e])
-            legal = set(int(a) for a in m["before"]["legal"][e][:n])
-            gh.child_visits.append([float(v) if a in legal else 0 for a, v in enumerate(m["child_visits"][e])])
-            gh.root_values.append(float(m["root_values"][e]))
-            gh.action_history.append(int(m["action"][e]))
-            gh.observation_history.append(m["next"]["obs"][e].copy())
-            gh.reward_history.append(float(m["reward"][e]))
-            gh.to_play_history.append(int(m["next"]["to_play"][e]))
-        return gh
+            self._len[idx] = 0
+            self._obs[idx, 0] = fresh["obs"][idx]
+            self._tp[idx, 0] = fresh["to_play"][idx]
+        self._cur = nxt
+        self.moves_played += self.E
 
     def close(self):
         self.envs.close()

@@ -1,0 +1,63 @@
+"""Whole self-play loop rate (search + env step + history filing), host-plugin envs vs device envs.
+
+    python tools/selfplay_rate.py [--game cartpole] [--envs 4096] [--moves 60]
+
+Prints one JSON line per actor kind: moves/s, simulations/s, finished games.  This is the loop the
+reference runs in self_play.py:34-113 (continuous_self_play), without the replay buffer hand-off."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+models = importlib.import_module("muzero-hypermodel_amd.models")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--game", default="cartpole")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--moves", type=int, default=60)
+    ap.add_argument("--kinds", default="host,device")
+    args = ap.parse_args()
+    mod = importlib.import_module(f"muzero-hypermodel_amd.games.{args.game}")
+    config = mod.MuZeroConfig()
+    torch.manual_seed(0)
+    weights = models.MuZeroNetwork(config).get_weights()
+    for kind in args.kinds.split(","):
+        if kind == "host":
+            actor = sp.BatchedSelfPlay({"weights": weights}, mod.Game, config, 0, args.envs)
+        else:
+            actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs)
+        done = [0]
+
+        def on_game(e, gh):
+            done[0] += 1
+
+        def on_games(batch):
+            done[0] += len(batch)
+
+        cb = dict(on_game=on_game) if kind in ("host", "device-lists") else dict(on_games=on_games)
+        for _ in range(5):
+            actor.step(1.0, None, **cb)
+        torch.cuda.synchronize()
+        done[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(args.moves):
+            actor.step(1.0, None, **cb)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        moves = args.moves * args.envs
+        print(json.dumps({"actor": kind, "game": args.game, "envs": args.envs, "moves_per_s": moves / dt,
+                          "simulations_per_s": moves * config.num_simulations / dt, "ms_per_move_step": 1e3 * dt / args.moves,
+                          "games_finished": done[0]}), flush=True)
+        actor.close()
+
+
+if __name__ == "__main__":
+    main()
