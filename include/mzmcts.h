@@ -226,6 +226,20 @@ int mzmcts_search_fused_fc(mzmcts_engine *engine, const float *observations, int
                            void *stream);
 /* Dynamic LDS bytes per workgroup the fused kernel would use (0 = not configured / does not fit). */
 int64_t mzmcts_fused_lds_bytes(mzmcts_engine *engine, int32_t hidden_in_lds);
+/* Two whole-move kernels exist.  GENERIC handles any MuZeroFullyConnectedNetwork (activations and weights
+ * in LDS).  NARROW handles networks whose every layer fits one 16-lane row (group_width 16, one hidden
+ * layer of <= 16 units per MLP -- none or one for the representation --, encoding_size + actions <= 16,
+ * observation <= 16 floats, support <= 32 logits: the reference's cartpole.py:61-71) with activations in
+ * registers; AUTO (default) picks NARROW when the network qualifies.  The lock-step mzmcts_fc_*_inference
+ * calls follow the same choice, so either fused kernel can be compared with the lock-step search bit for bit.
+ * publish_tree: 1 (default) = the fused kernel copies the whole tree to the HBM pools (mzmcts_export_tree,
+ * mzmcts_hidden_slab); 0 = only what MCTS.run's callers consume, the root's children and statistics. */
+#define MZMCTS_FUSED_AUTO 0
+#define MZMCTS_FUSED_GENERIC 1
+#define MZMCTS_FUSED_NARROW 2
+int mzmcts_set_fused_options(mzmcts_engine *engine, int32_t variant, int32_t publish_tree);
+/* The variant mzmcts_search_fused_fc would launch now: MZMCTS_FUSED_GENERIC / _NARROW, 0 = none fits. */
+int32_t mzmcts_fused_variant(mzmcts_engine *engine);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);

@@ -86,6 +86,8 @@ PROTOTYPES = {
     "mzmcts_fc_recurrent_inference": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "mzmcts_search_fused_fc": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void]),
     "mzmcts_fused_lds_bytes": (ctypes.c_int64, [c_void, ctypes.c_int32]),
+    "mzmcts_set_fused_options": (ctypes.c_int, [c_void, ctypes.c_int32, ctypes.c_int32]),
+    "mzmcts_fused_variant": (ctypes.c_int32, [c_void]),
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),

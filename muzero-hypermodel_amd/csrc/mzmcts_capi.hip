@@ -22,6 +22,7 @@
 
 #include "../../include/mzmcts.h"
 #include "fc_net_device.h"
+#include "narrow_device.h"
 #include "np_legacy_rng.h"
 #include "tree_layout.h"
 
@@ -32,6 +33,14 @@ hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const floa
                                float* hidden_out, hipStream_t stream);
 bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_in_lds, size_t lds_limit,
                        FusedLayout* out);
+bool narrow_supported(const TreeParams& p, const FcNet& net);
+bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit, NarrowLayout* out);
+hipError_t launch_search_fused_narrow(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
+                                      const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
+                                      int publish_tree, hipStream_t stream, const LaunchTiming* timing);
+hipError_t launch_fc_inference_narrow(const TreeParams& p, const FcNet& net, const float* weights, bool initial,
+                                      const float* in, const int64_t* action, float* value_logits, float* reward_logits,
+                                      float* policy_logits, float* hidden_out, hipStream_t stream);
 hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
                                   const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
                                   hipStream_t stream, const LaunchTiming* timing);
@@ -197,6 +206,9 @@ struct mzmcts_engine {
 
     // fully-connected network for the in-kernel inference paths
     bool fc_ready = false;
+    int fused_variant = MZMCTS_FUSED_AUTO;  // which whole-move kernel mzmcts_search_fused_fc launches
+    bool publish_tree = true;               // fused kernels copy the whole tree out (export_tree) or the root only
+    bool tree_published = true;             // false after a root-only fused search
     mz::FcNet fc{};
     const float* fc_weights = nullptr;
 
@@ -594,6 +606,7 @@ static int expand_roots_common(mzmcts_engine* eng, const float* value_logits, co
                                             injected, stream, scope.get()));
     }
     eng->roots_ready = true;
+    eng->tree_published = true;
     eng->sim = 0;
     return MZMCTS_OK;
 }
@@ -854,6 +867,9 @@ int mzmcts_last_paths(mzmcts_engine* eng, int32_t* depth, int32_t* actions, int3
 int mzmcts_export_tree(mzmcts_engine* eng, int32_t env, int32_t* visits, double* value_sum, double* prior,
                        double* reward, int32_t* child_node, void* stream_) {
     if (!eng || env < 0 || env >= eng->p.E) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_export_tree: bad env");
+    if (!eng->tree_published)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_export_tree: the last fused search published the root only "
+                                             "(mzmcts_set_fused_options(engine, variant, publish_tree = 1) keeps the tree)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const mz::TreeParams& p = eng->p;
     const int K = p.S + 1, A = p.A;
@@ -1008,13 +1024,49 @@ int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float
     return MZMCTS_OK;
 }
 
+// The narrow kernels (fused_narrow.hip) run when the network qualifies and the caller did not ask for the
+// generic ones; asking for them on a network that does not qualify is reported by mzmcts_set_fused_options.
+static bool use_narrow(const mzmcts_engine* eng) {
+    if (!eng->fc_ready || eng->fused_variant == MZMCTS_FUSED_GENERIC) return false;
+    mz::NarrowLayout lay{};
+    return mz::narrow_supported(eng->p, eng->fc) && mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &lay);
+}
+
+int mzmcts_set_fused_options(mzmcts_engine* eng, int32_t variant, int32_t publish_tree) {
+    if (!eng) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_fused_options: null engine");
+    if (variant != MZMCTS_FUSED_AUTO && variant != MZMCTS_FUSED_GENERIC && variant != MZMCTS_FUSED_NARROW)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_fused_options: unknown variant");
+    if (variant == MZMCTS_FUSED_NARROW) {
+        if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_fused_options: call mzmcts_fc_configure first");
+        mz::NarrowLayout lay{};
+        if (!mz::narrow_supported(eng->p, eng->fc) || !mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &lay))
+            return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_fused_options: the narrow kernel needs group_width 16, one hidden "
+                                                 "layer of <= 16 units per MLP, encoding + actions <= 16, support <= 32 logits");
+    }
+    eng->fused_variant = variant;
+    eng->publish_tree = publish_tree != 0;
+    return MZMCTS_OK;
+}
+
+int32_t mzmcts_fused_variant(mzmcts_engine* eng) {
+    if (!eng || !eng->fc_ready) return 0;
+    if (use_narrow(eng)) return MZMCTS_FUSED_NARROW;
+    mz::FusedLayout lay{};
+    return mz::plan_fused_layout(eng->p, eng->fc, true, kLdsPerWorkgroup, &lay) ? MZMCTS_FUSED_GENERIC : 0;
+}
+
 int mzmcts_fc_initial_inference(mzmcts_engine* eng, const float* observations, float* value_logits, float* reward_logits,
                                 float* policy_logits, float* hidden_out, void* stream) {
     if (!eng || !observations || !value_logits || !reward_logits || !policy_logits || !hidden_out)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: call mzmcts_fc_configure first");
-    MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, true, observations, nullptr, value_logits,
-                                        reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
+    if (use_narrow(eng))
+        MZ_HIP(eng, mz::launch_fc_inference_narrow(eng->p, eng->fc, eng->fc_weights, true, observations, nullptr,
+                                                   value_logits, reward_logits, policy_logits, hidden_out,
+                                                   static_cast<hipStream_t>(stream)));
+    else
+        MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, true, observations, nullptr, value_logits,
+                                            reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
     return MZMCTS_OK;
 }
 
@@ -1023,13 +1075,23 @@ int mzmcts_fc_recurrent_inference(mzmcts_engine* eng, const float* hidden, const
     if (!eng || !hidden || !action || !value_logits || !reward_logits || !policy_logits || !hidden_out)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: call mzmcts_fc_configure first");
-    MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, false, hidden, action, value_logits,
-                                        reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
+    if (use_narrow(eng))
+        MZ_HIP(eng, mz::launch_fc_inference_narrow(eng->p, eng->fc, eng->fc_weights, false, hidden, action, value_logits,
+                                                   reward_logits, policy_logits, hidden_out,
+                                                   static_cast<hipStream_t>(stream)));
+    else
+        MZ_HIP(eng, mz::launch_fc_inference(eng->p, eng->fc, eng->fc_weights, false, hidden, action, value_logits,
+                                            reward_logits, policy_logits, hidden_out, static_cast<hipStream_t>(stream)));
     return MZMCTS_OK;
 }
 
 int64_t mzmcts_fused_lds_bytes(mzmcts_engine* eng, int32_t hidden_in_lds) {
     if (!eng || !eng->fc_ready) return 0;
+    if (use_narrow(eng)) {
+        mz::NarrowLayout nl{};
+        mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
+        return nl.total_bytes;
+    }
     mz::FusedLayout lay{};
     if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay)) return 0;
     return lay.total_bytes;
@@ -1040,15 +1102,23 @@ int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: call mzmcts_fc_configure first");
     if (!eng->search_begun) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc called before begin_search");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    mz::FusedLayout lay{};
-    if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay))
-        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: the trees of one workgroup do not fit in 160 KB of LDS "
-                                             "(use a wider group_width or the lock-step path)");
-    {
+    const double* noise = eng->noise_this_search ? eng->d_noise : nullptr;
+    if (use_narrow(eng)) {
+        mz::NarrowLayout nl{};
+        mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
         ProfScope scope(eng, stream, kProfFused);
-        MZ_HIP(eng, mz::launch_search_fused_fc(eng->p, eng->fc, lay, eng->fc_weights, observations,
-                                               eng->noise_this_search ? eng->d_noise : nullptr, eng->d_skip, eng->p.S,
-                                               stream, scope.get()));
+        MZ_HIP(eng, mz::launch_search_fused_narrow(eng->p, eng->fc, nl, eng->fc_weights, observations, noise, eng->d_skip,
+                                                   eng->p.S, eng->publish_tree ? 1 : 0, stream, scope.get()));
+        eng->tree_published = eng->publish_tree;
+    } else {
+        mz::FusedLayout lay{};
+        if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay))
+            return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: the trees of one workgroup do not fit in 160 KB of "
+                                                 "LDS (use a wider group_width or the lock-step path)");
+        ProfScope scope(eng, stream, kProfFused);
+        MZ_HIP(eng, mz::launch_search_fused_fc(eng->p, eng->fc, lay, eng->fc_weights, observations, noise, eng->d_skip,
+                                               eng->p.S, stream, scope.get()));
+        eng->tree_published = true;
     }
     eng->roots_ready = true;
     eng->sim = eng->p.S;

@@ -1,0 +1,430 @@
+// narrow_device.h -- the "narrow" fully-connected fast path: MuZeroFullyConnectedNetwork (reference
+// models.py:84-195) for networks whose every layer fits one 16-lane DPP row, plus the tree walk and
+// the backup written for a tree that lives in LDS and is owned by exactly that row.
+//
+// Why a second implementation next to fc_net_device.h / tree_device.h: at the headline configuration
+// (4096 envs on 256 CUs) every SIMD runs ONE wavefront, so a move costs exactly the length of one
+// tree's dependent instruction chain.  The generic code pays an LDS round trip (~130 cycles, nobody to
+// hide it) per layer boundary, per backup hand-over and per cross-lane publish; here
+//   * a layer is 16 `v_fmac_f32` with a DPP row-rotate on the activation operand: lane j holds neuron
+//     j's activation, step r multiplies the activation of lane src_r(j) with W[j][src_r(j)], whose
+//     copy in LDS is laid out in rotation order -- activations never leave the registers;
+//   * the value recursion of the backup runs down the lanes with `row_shl:1` (lane = path level);
+//   * the descent keeps per child the term r + discount * (+-Q) the backup already computes for the
+//     min-max statistics (bit-identical to recomputing it in ucb_score) and reads
+//     (log(..)+init) * (sqrt(N) / (n+1)) from a table over (N, n) built with the same IEEE operations,
+//     leaving one fp64 division (the normalisation) on the chain.
+// The fp64 tree arithmetic performs the reference's operations on the reference's operands, so the
+// bit-exactness contract of tree_device.h holds unchanged; the fp32 network accumulates each neuron in
+// rotation order with FMAs, which moves logits by ~1e-7 (inside the 1e-5 bar of BASELINE.json).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fc_net_device.h"
+#include "tree_device.h"
+
+namespace mz {
+
+constexpr int kRow = 16;  // lanes per tree == one DPP row
+
+// units of 16x16 weights, in rotation order; slots that a network does not use stay zero
+enum NarrowUnit : int {
+    kURepr0 = 0,  // representation: first Linear (obs -> hidden, or obs -> enc when there is no hidden layer)
+    kURepr1,      // representation: hidden -> enc (only with a hidden layer)
+    kUDyn1,       // dynamics: [state | one-hot action] -> hidden
+    kUDyn2,       // dynamics: hidden -> enc
+    kURew1,
+    kUVal1,
+    kUPol1,
+    kURew2a,      // reward support logits 0..15
+    kURew2b,      // reward support logits 16..31
+    kUVal2a,
+    kUVal2b,
+    kUPol2,
+    kNarrowUnits
+};
+
+struct NarrowLayout {
+    uint32_t off_pbc;      // double[2][S+1]
+    uint32_t off_pbc2;     // double[(S+1)(S+2)/2] or 0xffffffff
+    uint32_t off_units;    // float4[kNarrowUnits][4][16]
+    uint32_t off_bias;     // float[kNarrowUnits][16]
+    uint32_t off_trees;
+    uint32_t tree_bytes;
+    uint32_t off_vterm;    // within a tree region: double[(S+1)][A]
+    uint32_t off_path;     // int32[S]
+    uint32_t off_hidden;   // float[(S+1)][enc]
+    uint32_t off_misc;     // int32[16] root actions | float[16] root policy logits
+    uint32_t total_bytes;
+    int32_t waves;         // wavefronts (= 4 trees each) per workgroup
+};
+
+template <int R>
+__device__ __forceinline__ int row_ror_bits(int v) {
+    if constexpr (R == 0) return v;
+    else return __builtin_amdgcn_update_dpp(0, v, 0x120 + R, 0xF, 0xF, true);  // row_ror:R
+}
+template <int R>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, row_ror_bits<R>(__builtin_bit_cast(int, v)));
+}
+// lane i of a row receives lane i+1's value; lane 15 receives 0
+__device__ __forceinline__ int row_shl1_bits(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+__device__ __forceinline__ double row_shl1(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = row_shl1_bits(static_cast<int>(bits & 0xffffffffll));
+    const int hi = row_shl1_bits(static_cast<int>(bits >> 32));
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+// OR over the row, every lane receives the result
+__device__ __forceinline__ int row_or(int v) {
+    v |= partner_bits<1>(v);
+    v |= partner_bits<2>(v);
+    v |= partner_bits<4>(v);
+    v |= partner_bits<8>(v);
+    return v;
+}
+
+// ---- weights in rotation order -----------------------------------------------------------------------
+struct NarrowUnitSource {
+    FcLayer layer;
+    int out_base;  // neuron of lane 0
+    bool active;
+};
+
+__device__ __forceinline__ NarrowUnitSource narrow_unit_source(const FcNet& net, int u) {
+    NarrowUnitSource s{};
+    s.active = true;
+    s.out_base = 0;
+    const bool repr_hidden = net.repr.n_layers == 2;
+    switch (u) {
+        case kURepr0: s.layer = net.repr.layer[0]; break;
+        case kURepr1: s.layer = net.repr.layer[1]; s.active = repr_hidden; break;
+        case kUDyn1: s.layer = net.dyn.layer[0]; break;
+        case kUDyn2: s.layer = net.dyn.layer[1]; break;
+        case kURew1: s.layer = net.reward.layer[0]; break;
+        case kUVal1: s.layer = net.value.layer[0]; break;
+        case kUPol1: s.layer = net.policy.layer[0]; break;
+        case kURew2a: s.layer = net.reward.layer[1]; break;
+        case kURew2b: s.layer = net.reward.layer[1]; s.out_base = kRow; s.active = net.F > kRow; break;
+        case kUVal2a: s.layer = net.value.layer[1]; break;
+        case kUVal2b: s.layer = net.value.layer[1]; s.out_base = kRow; s.active = net.F > kRow; break;
+        default: s.layer = net.policy.layer[1]; break;
+    }
+    return s;
+}
+
+// All threads of the workgroup; the caller synchronises afterwards.  Thread t stages for lane j = t % 16
+// the 16 weights of its neuron in the order its rotate steps will meet the activations: the source lane of
+// step r is measured by rotating the lane index itself, so the table is right by construction.
+__device__ __forceinline__ void stage_narrow_units(const FcNet& net, const float* __restrict__ flat, float4* units,
+                                                   float* bias, int tid, int nthreads) {
+    const int j = tid & (kRow - 1);
+    int src[kRow];
+#define MZ_SRC(R) src[R] = row_ror_bits<R>(j);
+    MZ_SRC(0) MZ_SRC(1) MZ_SRC(2) MZ_SRC(3) MZ_SRC(4) MZ_SRC(5) MZ_SRC(6) MZ_SRC(7)
+    MZ_SRC(8) MZ_SRC(9) MZ_SRC(10) MZ_SRC(11) MZ_SRC(12) MZ_SRC(13) MZ_SRC(14) MZ_SRC(15)
+#undef MZ_SRC
+    for (int u = tid / kRow; u < kNarrowUnits; u += nthreads / kRow) {
+        const NarrowUnitSource s = narrow_unit_source(net, u);
+        const int n = s.out_base + j;
+        const bool row_ok = s.active && n < s.layer.out;
+        float w[kRow];
+#pragma unroll
+        for (int r = 0; r < kRow; ++r) {
+            const int k = src[r];
+            w[r] = (row_ok && k < s.layer.in) ? flat[s.layer.w_off + n * s.layer.in + k] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) units[(u * 4 + c) * kRow + j] = float4{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
+        bias[u * kRow + j] = row_ok ? flat[s.layer.b_off + n] : 0.f;
+    }
+}
+
+// bias + W x for this lane's neuron of unit U; x holds the layer input, element k in lane k (0 beyond it)
+template <int U>
+__device__ __forceinline__ float narrow_unit(const float4* units, const float* bias, float x, int j) {
+    const float4* w = units + (U * 4) * kRow + j;
+    const float4 w0 = w[0], w1 = w[kRow], w2 = w[2 * kRow], w3 = w[3 * kRow];
+    float a = bias[U * kRow + j];
+    float b = 0.f;
+    a = fmaf(row_ror<0>(x), w0.x, a);
+    b = fmaf(row_ror<1>(x), w0.y, b);
+    a = fmaf(row_ror<2>(x), w0.z, a);
+    b = fmaf(row_ror<3>(x), w0.w, b);
+    a = fmaf(row_ror<4>(x), w1.x, a);
+    b = fmaf(row_ror<5>(x), w1.y, b);
+    a = fmaf(row_ror<6>(x), w1.z, a);
+    b = fmaf(row_ror<7>(x), w1.w, b);
+    a = fmaf(row_ror<8>(x), w2.x, a);
+    b = fmaf(row_ror<9>(x), w2.y, b);
+    a = fmaf(row_ror<10>(x), w2.z, a);
+    b = fmaf(row_ror<11>(x), w2.w, b);
+    a = fmaf(row_ror<12>(x), w3.x, a);
+    b = fmaf(row_ror<13>(x), w3.y, b);
+    a = fmaf(row_ror<14>(x), w3.z, a);
+    b = fmaf(row_ror<15>(x), w3.w, b);
+    return a + b;
+}
+
+__device__ __forceinline__ float narrow_elu(float v) { return v > 0.f ? v : elu_negative(v); }
+
+// models.py:137-145 / 161-168: min-max rescale of the first `enc` lanes to [0, 1]; lanes beyond read 0
+__device__ __forceinline__ float narrow_rescale(float raw, int enc, int j) {
+    const bool in = j < enc;
+    float mn = in ? raw : INFINITY, mx = in ? raw : -INFINITY;
+    MZ_BUTTERFLY(kRow, kRow, (mn = fminf(mn, partner<M>(mn)), mx = fmaxf(mx, partner<M>(mx))));
+    float scale = mx - mn;
+    if (scale < 1e-5f) scale += 1e-5f;
+    return in ? (raw - mn) / scale : 0.f;
+}
+
+struct NarrowHeads {
+    float norm;             // next hidden state (lanes < enc)
+    float reward_a, reward_b, value_a, value_b;  // support logits: element j and 16 + j
+    float policy;           // logits, lanes < A
+};
+
+// models.py:147-170, 192-195 recurrent_inference; x0 = [hidden | one-hot(action)] across the lanes
+__device__ __forceinline__ NarrowHeads narrow_recurrent(const float4* units, const float* bias, int enc, bool wide_support,
+                                                        float x0, int j) {
+    NarrowHeads h{};
+    const float d1 = narrow_elu(narrow_unit<kUDyn1>(units, bias, x0, j));
+    const float raw = narrow_unit<kUDyn2>(units, bias, d1, j);
+    h.norm = narrow_rescale(raw, enc, j);
+    // the reward head reads the UN-normalised next state (models.py:157-159)
+    const float r1 = narrow_elu(narrow_unit<kURew1>(units, bias, raw, j));
+    const float v1 = narrow_elu(narrow_unit<kUVal1>(units, bias, h.norm, j));
+    const float p1 = narrow_elu(narrow_unit<kUPol1>(units, bias, h.norm, j));
+    h.reward_a = narrow_unit<kURew2a>(units, bias, r1, j);
+    h.value_a = narrow_unit<kUVal2a>(units, bias, v1, j);
+    h.policy = narrow_unit<kUPol2>(units, bias, p1, j);
+    h.reward_b = 0.f;
+    h.value_b = 0.f;
+    if (wide_support) {
+        h.reward_b = narrow_unit<kURew2b>(units, bias, r1, j);
+        h.value_b = narrow_unit<kUVal2b>(units, bias, v1, j);
+    }
+    return h;
+}
+
+// models.py:172-190 initial_inference (reward = log(one_hot(centre)), decodes to exactly 0)
+__device__ __forceinline__ NarrowHeads narrow_initial(const float4* units, const float* bias, int enc, bool wide_support,
+                                                      bool repr_hidden, float obs, int j) {
+    NarrowHeads h{};
+    float raw = narrow_unit<kURepr0>(units, bias, obs, j);
+    if (repr_hidden) raw = narrow_unit<kURepr1>(units, bias, narrow_elu(raw), j);
+    h.norm = narrow_rescale(raw, enc, j);
+    const float v1 = narrow_elu(narrow_unit<kUVal1>(units, bias, h.norm, j));
+    const float p1 = narrow_elu(narrow_unit<kUPol1>(units, bias, h.norm, j));
+    h.value_a = narrow_unit<kUVal2a>(units, bias, v1, j);
+    h.policy = narrow_unit<kUPol2>(units, bias, p1, j);
+    h.value_b = wide_support ? narrow_unit<kUVal2b>(units, bias, v1, j) : 0.f;
+    h.reward_a = 0.f;
+    h.reward_b = 0.f;
+    return h;
+}
+
+// models.py:641-662 support_to_scalar for two logit vectors held in registers (element j in `a`, 16 + j in
+// `b`); the two reductions are interleaved.  Every lane of the row receives both results.
+__device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra, float rb, int F, int support, int j,
+                                                    float& value, float& reward) {
+    const bool in_a = j < F, in_b = kRow + j < F;
+    const float xva = in_a ? va : -INFINITY, xvb = in_b ? vb : -INFINITY;
+    const float xra = in_a ? ra : -INFINITY, xrb = in_b ? rb : -INFINITY;
+    float mv = fmaxf(xva, xvb), mr = fmaxf(xra, xrb);
+    MZ_BUTTERFLY(kRow, kRow, (mv = fmaxf(mv, partner<M>(mv)), mr = fmaxf(mr, partner<M>(mr))));
+    const float eva = in_a ? expf(xva - mv) : 0.f, evb = in_b ? expf(xvb - mv) : 0.f;
+    const float era = in_a ? expf(xra - mr) : 0.f, erb = in_b ? expf(xrb - mr) : 0.f;
+    float sv = eva + evb, sr = era + erb;
+    MZ_BUTTERFLY(kRow, kRow, (sv = sv + partner<M>(sv), sr = sr + partner<M>(sr)));
+    const float iv = 1.0f / sv, ir = 1.0f / sr;
+    const float fa = static_cast<float>(j - support), fb = static_cast<float>(kRow + j - support);
+    float av = fa * (eva * iv) + fb * (evb * iv);
+    float ar = fa * (era * ir) + fb * (erb * ir);
+    MZ_BUTTERFLY(kRow, kRow, (av = av + partner<M>(av), ar = ar + partner<M>(ar)));
+    value = inverse_value_transform(av);
+    reward = inverse_value_transform(ar);
+}
+
+// fp32 softmax over the lanes with valid == true (Node.expand, self_play.py:461-463), widened like .tolist()
+__device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
+    float m = valid ? logit : -INFINITY;
+    MZ_BUTTERFLY(kRow, kRow, m = fmaxf(m, partner<M>(m)));
+    const float e = valid ? expf(logit - m) : 0.f;
+    float s = e;
+    MZ_BUTTERFLY(kRow, kRow, s = s + partner<M>(s));
+    return static_cast<double>(e * (1.0f / s));
+}
+
+// ---- tree in LDS with the per-child value term ---------------------------------------------------------
+struct LdsTreeV {
+    static constexpr bool kInLds = true;
+    uint8_t* blocks;
+    uint32_t block_stride;
+    uint32_t links_offset;
+    double* vterm_base;   // [(S+1)][A]
+    int32_t* path;
+    int A;
+    __device__ __forceinline__ ChildStats* stats(int k) const {
+        return reinterpret_cast<ChildStats*>(blocks + static_cast<uint32_t>(k) * block_stride);
+    }
+    __device__ __forceinline__ ChildLinks* links(int k) const {
+        return reinterpret_cast<ChildLinks*>(blocks + static_cast<uint32_t>(k) * block_stride + links_offset);
+    }
+    __device__ __forceinline__ double* vterm(int k) const { return vterm_base + k * A; }
+    __device__ __forceinline__ void path_store(int level, int packed) const { path[level] = packed; }
+    __device__ __forceinline__ int path_load(int level) const { return path[level]; }
+};
+
+// The `while node.expanded()` loop (self_play.py:321-335) with select_child / ucb_score
+// (self_play.py:364-405) for A <= SPAN <= 16 children, child c in lane c of the tree's row.
+//   prior_score = ((log(..)+init) * (sqrt(N)/(n+1))) * prior      table entry [N][n] (same two IEEE ops)
+//   value_score = normalize(vterm)                                  vterm = r + discount*(+-Q), stored by the backup
+// Scores, tie lists and RNG draws are those of tree_device.h's descend(), bit for bit.
+template <int SPAN, bool PBC2>
+__device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
+                                               int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
+                                               int32_t& mt_pos, uint32_t& words, int j, int group_base,
+                                               int32_t* error_flag) {
+    const bool has_range = mm.maximum > mm.minimum;
+    const double range = mm.maximum - mm.minimum;
+    int n_children = n_root_children;
+    int k = 0, N = sim, depth = 0, slot = 0;
+    for (;;) {
+        const bool valid = j < n_children;
+        const int c = valid ? j : 0;
+        const ChildStats* st = acc.stats(k) + c;
+        const ChildLinks* lk = acc.links(k) + c;
+        const double prior = st->prior;
+        const int visits = lk->visits;
+        const int child = lk->child_node;
+        const double vt = acc.vterm(k)[c];
+        double pb;
+        if constexpr (PBC2) {
+            pb = pbc2[((N * (N + 1)) >> 1) + visits];
+        } else {
+            pb = pbc[N];
+            pb = pb * (pbc[S + 1 + N] / static_cast<double>(visits + 1));
+        }
+        const double prior_score = pb * prior;
+        const double normalized = (vt - mm.minimum) / range;  // discarded unless visited and max > min
+        const double value_score = visits > 0 ? (has_range ? normalized : vt) : 0.0;
+        const double score = valid ? prior_score + value_score : -INFINITY;
+        double best = score;
+        MZ_BUTTERFLY(SPAN, SPAN, best = fmax(best, partner<M>(best)));
+
+        const bool is_max = valid && (score == best);
+        const unsigned long long ballot = __ballot(is_max);
+        unsigned int mask = static_cast<unsigned int>(ballot >> group_base) & ((1u << SPAN) - 1u);
+        const int n_ties = __popc(mask);
+        if (n_ties > 1) {  // numpy.random.choice over the tie list (self_play.py:372-378)
+            int r = 0;
+            if (j == 0) r = static_cast<int>(mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words));
+            r = row_or(r);
+            for (int i = 0; i < r; ++i) mask &= mask - 1u;
+        } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
+            if (j == 0) atomicOr(error_flag, 1);
+            mask = 1u;
+        }
+        slot = __ffs(static_cast<int>(mask)) - 1;
+        const int packed = row_or((j == slot) ? (visits | ((child + 1) << 16)) : 0);
+        const int sel_visits = packed & 0xffff;
+        const int sel_child = (packed >> 16) - 1;
+        if (j == 0) acc.path_store(depth, (k << 16) | slot);
+        ++depth;
+        if (sel_child < 0) break;
+        if (depth > sim) {  // cannot happen on a consistent tree; guarantees every wave leaves the loop
+            if (j == 0) atomicOr(error_flag, 2);
+            break;
+        }
+        k = sel_child;
+        N = sel_visits;
+        n_children = A;
+    }
+    return Descent{depth, k, slot};
+}
+
+// backpropagate (self_play.py:407-431) for a tree in LDS, lane = path level (16 levels per round, leaf
+// side first).  Every lane fetches its node; the value recursion `value = (+-r) + discount * value` runs
+// down the lanes through row_shl:1 (each step recomputes all lanes; a lane is final one step after its
+// upper neighbour, and recomputing a final lane reproduces it); then every lane finishes its own node
+// (the division for the node's mean runs in parallel over the levels) and stores the child's value term
+// for the next descents.  min-max statistics are reduced over the row (max / min are exact under any
+// association) into every lane.  Same operations on the same operands as the sequential walk.
+__device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int sim, double value, float reward_f,
+                                           bool two_player, double discount, MinMax& mm, double& root_value_sum,
+                                           double root_reward, int j) {
+    const int k_new = sim + 1;
+    double carry = value;  // value arriving at the deepest node not yet processed (uniform over the row)
+    double seen_max = -INFINITY, seen_min = INFINITY;
+    double into_root = 0.0;
+    for (int base = ((depth - 1) >> 4) << 4; base >= 0; base -= kRow) {
+        const int cnt = (depth - base < kRow) ? depth - base : kRow;  // levels base .. base + cnt - 1
+        const int level = base + j;
+        const bool mine = j < cnt;
+        const bool leaf = level == depth - 1;
+        const int packed = acc.path_load(mine ? level : base);
+        const int slot = packed & 0xffff;
+        const int kk = packed >> 16;
+        ChildStats* st = acc.stats(kk) + slot;
+        ChildLinks* lk = acc.links(kk) + slot;
+        double vs = st->value_sum;
+        float r_f = lk->reward;
+        int visits = lk->visits;
+        if (leaf) {  // first visit of the new leaf: it carries the reward just predicted
+            vs = 0.0;
+            r_f = reward_f;
+            visits = 0;
+        }
+        const double r = static_cast<double>(r_f);
+        const bool same = ((depth - (level + 1)) & 1) == 0;  // node.to_play == to_play of the leaf
+        const double r_signed = two_player ? (same ? -r : r) : r;
+        double val = carry;
+        const bool is_top = j >= cnt - 1;
+        for (int s = cnt - 1; s > 0; --s) {
+            const double passed = row_shl1(r_signed + discount * val);
+            val = is_top ? val : passed;
+        }
+        const double leaving = r_signed + discount * val;  // lane 0: the value arriving one level up
+        if (mine) {
+            const double vs_new = vs + ((two_player && !same) ? -val : val);
+            const int visits_new = visits + 1;
+            const double q = vs_new / static_cast<double>(visits_new);
+            const double seen = r + discount * (two_player ? -q : q);
+            st->value_sum = vs_new;
+            if (leaf)
+                *lk = ChildLinks{reward_f, 1, k_new, 0};
+            else
+                lk->visits = visits_new;
+            acc.vterm(kk)[slot] = seen;
+            seen_max = fmax(seen_max, seen);
+            seen_min = fmin(seen_min, seen);
+        }
+        if (base > 0)
+            carry = __shfl(leaving, 0, kRow);
+        else
+            into_root = leaving;
+    }
+    // root (tree depth 0)
+    if (j == 0) {
+        const double n_root = static_cast<double>(sim + 1);
+        double seen;
+        if (!two_player) {
+            root_value_sum += into_root;
+            seen = root_reward + discount * (root_value_sum / n_root);
+        } else {
+            const bool same = (depth & 1) == 0;
+            root_value_sum += same ? into_root : -into_root;
+            seen = root_reward + discount * -(root_value_sum / n_root);
+        }
+        seen_max = fmax(seen_max, seen);
+        seen_min = fmin(seen_min, seen);
+    }
+    MZ_BUTTERFLY(kRow, kRow, (seen_max = fmax(seen_max, partner<M>(seen_max)), seen_min = fmin(seen_min, partner<M>(seen_min))));
+    mm.maximum = fmax(mm.maximum, seen_max);
+    mm.minimum = fmin(mm.minimum, seen_min);
+}
+
+}  // namespace mz

@@ -323,6 +323,16 @@ class BatchedMCTS:
             g <<= 1
         return g
 
+    FUSED_VARIANTS = {"auto": 0, "generic": 1, "narrow": 2}
+
+    def set_fused_options(self, variant="auto", publish_tree=True):
+        """Which whole-move kernel `search_fused` launches ("auto" | "generic" | "narrow", include/mzmcts.h) and
+        whether it copies the whole tree out (export_tree / hidden pool) or only the root's children."""
+        self._check(self._lib.mzmcts_set_fused_options(self._h, self.FUSED_VARIANTS[variant], 1 if publish_tree else 0))
+
+    def fused_variant(self):
+        return {0: None, 1: "generic", 2: "narrow"}[int(self._lib.mzmcts_fused_variant(self._h))]
+
     def fused_lds_bytes(self, hidden_in_lds=True):
         return int(self._lib.mzmcts_fused_lds_bytes(self._h, 1 if hidden_in_lds else 0))
 

@@ -44,9 +44,11 @@ def test_fc_kernels_match_torch_and_reference(eng, models_mod):
     model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
     fx = load_golden("g2_fc_inference")
     E = len(fx["obs"])
-    for group in (0, 4, 16):
+    for group, variant in ((0, "auto"), (4, "auto"), (16, "generic"), (16, "narrow")):
         engine = eng.BatchedMCTS(config, E, group_width=group)
         engine.configure_fused_fc(model)
+        engine.set_fused_options(variant)
+        assert engine.fused_variant() == ("narrow" if variant == "narrow" else "generic")
         v, r, p, h = engine.fc_initial_inference(torch.from_numpy(fx["obs"]).cuda())
         for got, key in ((v, "init_value"), (p, "init_policy"), (h, "init_hidden")):
             np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=1e-5, atol=1e-5, err_msg=key)
@@ -62,8 +64,9 @@ def test_fc_kernels_match_torch_and_reference(eng, models_mod):
         engine.close()
 
 
-@pytest.mark.parametrize("group,hidden_in_lds", [(0, True), (0, False), (4, True), (8, True), (16, False)])
-def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds):
+@pytest.mark.parametrize("group,hidden_in_lds,variant", [(0, True, "auto"), (0, False, "auto"), (4, True, "auto"),
+                                                         (8, True, "auto"), (16, False, "generic"), (16, True, "narrow")])
+def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds, variant):
     config = cartpole_config()
     model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
     fx = load_golden("g4_cartpole_traces")
@@ -77,9 +80,11 @@ def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds
     for fused in (False, True):
         engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=group)
         engine.configure_fused_fc(model)
+        engine.set_fused_options(variant)
         engine.fused_hidden_in_lds = hidden_in_lds
         if fused:
             assert engine.fused_lds_bytes(hidden_in_lds) > 0
+            assert engine.fused_variant() == ("narrow" if variant == "narrow" else "generic")
         moves = []
         for move in range(2):                   # second move: RNG mirrors must still be in step
             run = engine.search_fused if fused else engine.search_lockstep_fc
@@ -98,13 +103,16 @@ def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds
         assert np.array_equal(a_pool, b_pool)   # every hidden state of every tree
 
 
-def test_fused_vs_reference_traces(eng, models_mod):
+@pytest.mark.parametrize("group,variant", [(4, "generic"), (16, "narrow")])
+def test_fused_vs_reference_traces(eng, models_mod, group, variant):
     config = cartpole_config()
     model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
     fx = load_golden("g4_cartpole_traces")
     T = len(fx["seed"])
-    engine = eng.BatchedMCTS(config, T, seeds=[int(s) for s in fx["seed"]], group_width=4)
+    engine = eng.BatchedMCTS(config, T, seeds=[int(s) for s in fx["seed"]], group_width=group)
     engine.configure_fused_fc(model)
+    engine.set_fused_options(variant, publish_tree=False)
+    assert engine.fused_variant() == variant
     st = engine.search(model, fx["obs"], [[0, 1]] * T, [0] * T, True)      # dispatches to the fused kernel
     cv, rv = engine.search_statistics()
     actions, _ = engine.sample_actions(fx["temperature"].tolist())
@@ -125,7 +133,8 @@ def test_fused_vs_reference_traces(eng, models_mod):
     assert agree >= 0.8 * T
 
 
-def test_fused_full_size_invariants_and_determinism(eng, models_mod):
+@pytest.mark.parametrize("group", [4, 16])
+def test_fused_full_size_invariants_and_determinism(eng, models_mod, group):
     config = cartpole_config()
     model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
     E, S = 4096, config.num_simulations
@@ -133,9 +142,14 @@ def test_fused_full_size_invariants_and_determinism(eng, models_mod):
     legal = np.tile(np.array([0, 1], dtype=np.int32), (E, 1))
     runs = []
     for _ in range(2):
-        engine = eng.BatchedMCTS(config, E, group_width=4)
+        engine = eng.BatchedMCTS(config, E, group_width=group)
         engine.configure_fused_fc(model)
+        engine.set_fused_options("auto", publish_tree=False)
+        assert engine.fused_variant() == ("narrow" if group == 16 else "generic")
         st = copy_stats(engine.search_fused(obs, legal, [0] * E, True, num_legal=np.full(E, 2, np.int32)))
+        if group == 16:
+            with pytest.raises(RuntimeError, match="published the root only"):
+                engine.export_tree(0)
         runs.append(st)
         engine.close()
     st = runs[0]
@@ -146,13 +160,14 @@ def test_fused_full_size_invariants_and_determinism(eng, models_mod):
         assert np.array_equal(st[key], runs[1][key]), key
 
 
-def test_fused_inactive_envs_and_weight_refresh(eng, models_mod):
+@pytest.mark.parametrize("group", [4, 16])
+def test_fused_inactive_envs_and_weight_refresh(eng, models_mod, group):
     config = cartpole_config()
     model, weights = cartpole_model_and_weights(models_mod, config, "cuda")
     E = 48
     obs = torch.from_numpy(np.random.RandomState(1).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).cuda()
     legal = [[0, 1] if e % 5 else [] for e in range(E)]
-    engine = eng.BatchedMCTS(config, E, group_width=4)
+    engine = eng.BatchedMCTS(config, E, group_width=group)
     flat = engine.configure_fused_fc(model)
     st1 = copy_stats(engine.search_fused(obs, legal, [0] * E, True))
     for e in range(E):
@@ -183,12 +198,28 @@ def fc_variant(name):
         cfg.fc_value_layers = []
         cfg.fc_policy_layers = [70]           # more neurons than 4 x 16 lanes: multi-pass phases
         cfg.support_size = 7
+    elif name in ("narrow_2p", "narrow_1p"):
+        # shapes the narrow (register-resident) kernel accepts besides cartpole's own
+        cfg = cartpole_config()
+        two = name == "narrow_2p"
+        cfg.observation_shape = (1, 1, 12) if two else (1, 3, 2)
+        cfg.action_space = list(range(5 if two else 3))
+        cfg.players = list(range(2 if two else 1))
+        cfg.encoding_size = 10 if two else 5
+        cfg.fc_representation_layers = [11] if two else []
+        cfg.fc_dynamics_layers = [16] if two else [7]
+        cfg.fc_reward_layers = [12] if two else [16]
+        cfg.fc_value_layers = [9] if two else [4]
+        cfg.fc_policy_layers = [16] if two else [3]
+        cfg.support_size = 12 if two else 5          # 25 logits (two registers) / 11 logits (part of one)
+        cfg.num_simulations = 40
     cfg.network = "fullyconnected"
     return cfg
 
 
 @pytest.mark.parametrize("name,group", [("tictactoe_fc", 16), ("tictactoe_fc", 0), ("connect4_fc", 16),
-                                        ("cartpole_deep", 16), ("cartpole_deep", 4)])
+                                        ("cartpole_deep", 16), ("cartpole_deep", 4), ("narrow_2p", 16),
+                                        ("narrow_1p", 16)])
 def test_fused_other_fc_shapes(eng, models_mod, oracle, name, group):
     from parity_helpers import synthetic_model
     cfg = fc_variant(name)
@@ -211,6 +242,7 @@ def test_fused_other_fc_shapes(eng, models_mod, oracle, name, group):
         if mode != "torch":
             engine.configure_fused_fc(model)
             assert mode != "fused" or engine.fused_lds_bytes(True) > 0
+            assert engine.fused_variant() == ("narrow" if name.startswith("narrow") else "generic")
             run = engine.search_fused if mode == "fused" else engine.search_lockstep_fc
             st = copy_stats(run(torch.from_numpy(obs), legal, to_play, True))
         else:
