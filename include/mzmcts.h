@@ -241,6 +241,35 @@ int mzmcts_set_fused_options(mzmcts_engine *engine, int32_t variant, int32_t pub
 /* The variant mzmcts_search_fused_fc would launch now: MZMCTS_FUSED_GENERIC / _NARROW, 0 = none fits. */
 int32_t mzmcts_fused_variant(mzmcts_engine *engine);
 
+/* ---- batches of moves without host round trips ------------------------------------------------
+ * SelfPlay.play_game's per-move loop (self_play.py:129-182) for all envs, n_moves at a time, as kernels
+ * queued back to back on one stream: whole-move search (which also samples the move's action with
+ * SelfPlay.select_action on the tree's RNG stream), then whatever the caller queues on the same stream to
+ * turn those actions into the next observations (mzenv_step / mzenv_observe, include/mzenv.h), then the
+ * next search.  The host draws every move's Dirichlet noise up front and is not involved again until
+ * mzmcts_moves_collect.
+ *
+ * The pre-drawn noise assumes what the reference's RNG order implies for the common case -- search m spends
+ * one word on UCB tie-breaks (the first simulation's, when every root child still scores 0; tie-break words
+ * come ahead of the next Dirichlet draw in the stream) and select_action consumes 0 (T = 0) or 2 (T = 1) words.  Where that fails the env simply is not searched from the next move on (moves_done[e] <
+ * n_moves, its actions read -1: mzenv_step leaves such an env untouched) and the stream mirror is put back;
+ * the caller plays the missing moves in the next batch.  Played moves are bit-identical to the one-at-a-time
+ * path.  Legal action sets are those of a game whose action set does not change between moves (the Dirichlet
+ * dimension must be known in advance); temperature must be 0, 1 or +inf per env (+inf: one move per batch).
+ *   prepare   blocking host work (noise rows of the whole batch) + asynchronous uploads
+ *   enqueue   one search of the prepared batch, asynchronous; observations dev f32[E, obs]
+ *   actions   device pointer, i32[E], of move `move`'s sampled actions (valid until the next prepare)
+ *   collect   blocking: moves_done i32[E]; per move m < enqueued: actions i32[M,E], visits i32[M,E,A] (root
+ *             children by child slot, i.e. in legal-action order), root_value_sum f64[M,E],
+ *             root_predicted f32[M,E], max_depth i32[M,E]   (any output may be NULL) */
+int mzmcts_moves_prepare(mzmcts_engine *engine, int32_t n_moves, const int32_t *legal_actions,
+                         const int32_t *num_legal, const int32_t *to_play, int32_t add_exploration_noise,
+                         const double *temperature, void *stream);
+int mzmcts_moves_enqueue(mzmcts_engine *engine, const float *observations, void *stream);
+const int32_t *mzmcts_moves_actions(mzmcts_engine *engine, int32_t move);
+int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *actions, int32_t *visits,
+                         double *root_value_sum, float *root_predicted, int32_t *max_depth, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

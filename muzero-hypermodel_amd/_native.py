@@ -14,6 +14,7 @@ c_i32_p = ctypes.POINTER(ctypes.c_int32)
 c_i64_p = ctypes.POINTER(ctypes.c_int64)
 c_u32_p = ctypes.POINTER(ctypes.c_uint32)
 c_f64_p = ctypes.POINTER(ctypes.c_double)
+c_f32_p = ctypes.POINTER(ctypes.c_float)
 c_void = ctypes.c_void_p
 
 ABI_VERSION = 1
@@ -88,6 +89,10 @@ PROTOTYPES = {
     "mzmcts_fused_lds_bytes": (ctypes.c_int64, [c_void, ctypes.c_int32]),
     "mzmcts_set_fused_options": (ctypes.c_int, [c_void, ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_fused_variant": (ctypes.c_int32, [c_void]),
+    "mzmcts_moves_prepare": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_i32_p, ctypes.c_int32, c_f64_p, c_void]),
+    "mzmcts_moves_enqueue": (ctypes.c_int, [c_void, c_void, c_void]),
+    "mzmcts_moves_actions": (c_void, [c_void, ctypes.c_int32]),
+    "mzmcts_moves_collect": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_f64_p, c_f32_p, c_i32_p, c_void]),
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),

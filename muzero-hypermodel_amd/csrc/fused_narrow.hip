@@ -19,6 +19,13 @@ namespace mz {
 
 constexpr int kNarrowMaxThreads = 256;
 
+// lanes of the row that can hold a child (the kernel's SPAN template argument): 2, 4, 8 or 16
+static inline int narrow_vterm_shift(int A) {
+    int s = 1;
+    while ((1 << s) < A) ++s;
+    return s;
+}
+
 // Does this (engine, network) pair qualify for the narrow path?
 bool narrow_supported(const TreeParams& p, const FcNet& net) {
     auto one_hidden = [](const FcMlp& m) { return m.n_layers == 2 && m.layer[0].out <= kRow; };
@@ -55,7 +62,7 @@ bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit,
             lay.off_trees = static_cast<uint32_t>(off);
             size_t t = align16(static_cast<size_t>(p.S + 1) * p.block_stride);
             lay.off_vterm = static_cast<uint32_t>(t);
-            t = align16(t + sizeof(double) * static_cast<size_t>(p.S + 1) * p.A);
+            t = align16(t + sizeof(double) * static_cast<size_t>(p.S + 1) * (1u << narrow_vterm_shift(p.A)));
             lay.off_path = static_cast<uint32_t>(t);
             t = align16(t + sizeof(int32_t) * static_cast<size_t>(p.S));
             lay.off_hidden = static_cast<uint32_t>(t);
@@ -106,8 +113,7 @@ template <int SPAN, bool PBC2>
 __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
     TreeParams p, FcNet net, NarrowLayout lay, const float* __restrict__ weights,
     const float* __restrict__ observations,  // [E][obs]
-    const double* __restrict__ noise,        // [E][A] or null
-    const uint32_t* __restrict__ rng_skip, int n_sims, int publish_tree) {
+    MoveCtl ctl, int n_sims, int publish_tree) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     MZ_STAMP_DECL
     const double* pbc = reinterpret_cast<const double*>(smem + lay.off_pbc);
@@ -125,8 +131,13 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
     const int group_base = (threadIdx.x & 63) - j;  // lane of the row's first lane inside its wavefront
     if (e >= p.E) return;
     const int n_root = p.root_children[e];
-    if (j == 0) reset_search_state(p, e, rng_skip);
-    if (n_root == 0) return;
+    if (move_stalled(p, ctl, e, j)) return;
+    const double* noise = ctl.noise;
+    if (j == 0) reset_search_state(p, e, ctl.rng_skip);
+    if (n_root == 0) {
+        if (j == 0 && ctl.actions) ctl.actions[e] = -1;
+        return;
+    }
     // the DPP lane mappings the code below relies on (a wrong assumption must not pass silently)
     if (row_shl1_bits(j) != ((j + 1 < kRow) ? j + 1 : 0) || row_ror_bits<1>(j) != ((j + kRow - 1) & (kRow - 1))) {
         if (j == 0) atomicOr(p.error_flag, 8);
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
 
     uint8_t* region = smem + lay.off_trees + static_cast<size_t>(tree_in_block) * lay.tree_bytes;
     const LdsTreeV tree{region, p.block_stride, p.links_offset, reinterpret_cast<double*>(region + lay.off_vterm),
-                        reinterpret_cast<int32_t*>(region + lay.off_path), p.A};
+                        reinterpret_cast<int32_t*>(region + lay.off_path), SPAN == 2 ? 1 : SPAN == 4 ? 2 : SPAN == 8 ? 3 : 4};
     float* hidden_lds = reinterpret_cast<float*>(region + lay.off_hidden);
     int32_t* root_action_lds = reinterpret_cast<int32_t*>(region + lay.off_misc);
     float* root_logit_lds = reinterpret_cast<float*>(region + lay.off_misc) + kRow;
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
     for (int sim = 0; sim < n_sims; ++sim) {
         const Descent d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j,
-                                                  group_base, p.error_flag);
+                                                  group_base, p.error_flag MZ_DSTAMP_ARGS);
         MZ_STAMP(2);
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
         const float state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
@@ -207,11 +218,23 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
         p.min_max[e] = mm;
         p.max_depth[e] = max_depth;
         p.depth_sum[e] = depth_sum;
-        if (words) {
-            p.mt_pos[e] = mt_pos;
-            p.tie_words[e] = words;
+        uint32_t sample_words = 0;
+        if (ctl.temperature) {  // SelfPlay.select_action on the tree's own stream (kernel_common.h)
+            const ChildLinks* root_links = tree.links(0);
+            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, ctl.temperature[e],
+                                                  mt_key, &mt_pos, &sample_words);
+            if (ctl.actions) ctl.actions[e] = slot >= 0 ? root_action_lds[slot] : slot;
         }
+        if (words | sample_words) p.mt_pos[e] = mt_pos;
+        if (words) p.tie_words[e] = words;
+        if (ctl.tie_words) ctl.tie_words[e] = words;
+        if (ctl.sample_words) ctl.sample_words[e] = sample_words;
+        if (ctl.root_value_sum) ctl.root_value_sum[e] = root_value_sum;
+        if (ctl.root_predicted) ctl.root_predicted[e] = predicted;
+        if (ctl.max_depth) ctl.max_depth[e] = max_depth;
+        if (ctl.depth_sum) ctl.depth_sum[e] = static_cast<int32_t>(depth_sum);
     }
+    if (ctl.visits && j < p.A) ctl.visits[static_cast<size_t>(e) * p.A + j] = (j < n_root) ? tree.links(0)[j].visits : 0;
     const int block_words = static_cast<int>(p.block_stride / 16);
     const int n_blocks = publish_tree ? n_sims + 1 : 1;
     for (int t = j; t < n_blocks * block_words; t += kRow) {
@@ -286,8 +309,8 @@ hipError_t read_stamp_sums_narrow(unsigned long long* out, bool reset) {
 // -------------------------------------------------------------------------------------------------
 template <int SPAN>
 static hipError_t launch_narrow_span(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
-                                     const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
-                                     int publish_tree, hipStream_t stream, const LaunchTiming* timing) {
+                                     const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
+                                     hipStream_t stream, const LaunchTiming* timing) {
     const int threads = 64 * lay.waves;
     const int trees = threads / kRow;
     const int grid = (p.E + trees - 1) / trees;
@@ -296,7 +319,7 @@ static hipError_t launch_narrow_span(const TreeParams& p, const FcNet& net, cons
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lay.total_bytes));
         if (err != hipSuccess) return err;
         launch_kernel(kernel, dim3(grid), dim3(threads), lay.total_bytes, stream, timing, p, net, lay, weights, observations,
-                      noise, rng_skip, n_sims, publish_tree);
+                      ctl, n_sims, publish_tree);
         return hipGetLastError();
     };
     if (lay.off_pbc2 != 0xffffffffu) return go(search_fused_narrow_kernel<SPAN, true>);
@@ -304,12 +327,12 @@ static hipError_t launch_narrow_span(const TreeParams& p, const FcNet& net, cons
 }
 
 hipError_t launch_search_fused_narrow(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
-                                      const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
-                                      int publish_tree, hipStream_t stream, const LaunchTiming* timing) {
-    if (p.A <= 2) return launch_narrow_span<2>(p, net, lay, weights, observations, noise, rng_skip, n_sims, publish_tree, stream, timing);
-    if (p.A <= 4) return launch_narrow_span<4>(p, net, lay, weights, observations, noise, rng_skip, n_sims, publish_tree, stream, timing);
-    if (p.A <= 8) return launch_narrow_span<8>(p, net, lay, weights, observations, noise, rng_skip, n_sims, publish_tree, stream, timing);
-    return launch_narrow_span<16>(p, net, lay, weights, observations, noise, rng_skip, n_sims, publish_tree, stream, timing);
+                                      const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
+                                      hipStream_t stream, const LaunchTiming* timing) {
+    if (p.A <= 2) return launch_narrow_span<2>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
+    if (p.A <= 4) return launch_narrow_span<4>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
+    if (p.A <= 8) return launch_narrow_span<8>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
+    return launch_narrow_span<16>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
 }
 
 hipError_t launch_fc_inference_narrow(const TreeParams& p, const FcNet& net, const float* weights, bool initial,

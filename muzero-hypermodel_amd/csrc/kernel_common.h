@@ -50,6 +50,87 @@ __device__ __forceinline__ void reset_search_state(const TreeParams& p, int e, c
     p.leaf_parent[e] = 0;
 }
 
+// Per-move control block of the whole-move kernels.  A plain search passes the noise / rng_skip rows and
+// leaves the rest null.  A BATCH of moves queued back to back without host round trips
+// (mzmcts_moves_*, include/mzmcts.h) additionally lets the kernel
+//   * sample the move's action itself (SelfPlay.select_action, self_play.py:223-246) from the tree's RNG
+//     stream, so the next kernels (environment step, next search) can follow without the host;
+//   * refuse to search an env whose pre-drawn exploration noise has become invalid: the host draws the
+//     noise of move m+1 before move m has run, assuming how many RNG words search m spends on tie-breaks
+//     (they come ahead of the Dirichlet draw in the stream); when it spent a different number, the env
+//     stalls -- sticky flag, nothing consumed, nothing written -- and the host redraws from the true stream
+//     position after collecting the batch;
+//   * write the move's results into that move's slot of an output ring.
+struct MoveCtl {
+    const double* noise;          // [E][A] Dirichlet rows of this move, or null
+    const uint32_t* rng_skip;     // [E] words the host consumed since the device copy last moved
+    const double* temperature;    // [E]; null = the host samples the action
+    const int32_t* move_limit;    // [E] first move of the batch that must NOT be searched; null = no limit
+    uint8_t* stall;               // [E] sticky within a batch; null = never stall
+    int32_t move_index;
+    const uint32_t* expected_ties; // [E] tie-break words the previous search of the batch was assumed to consume;
+                                  //     null = this is the first move of the batch (nothing was assumed)
+    // this move's slot of the output ring (any may be null)
+    int32_t* actions;             // [E] sampled action (-1: not searched)
+    int32_t* visits;              // [E][A] root children visit counts, by child slot
+    double* root_value_sum;       // [E]
+    float* root_predicted;        // [E]
+    int32_t* max_depth;           // [E]
+    uint32_t* tie_words;          // [E] RNG words the search consumed (tie-breaks)
+    uint32_t* sample_words;       // [E] RNG words the action sampling consumed
+    int32_t* depth_sum;           // [E] sum of the S descent depths
+};
+
+// Group-uniform: true = this env must not be searched in this move (see MoveCtl).
+__device__ __forceinline__ bool move_stalled(const TreeParams& p, const MoveCtl& ctl, int e, int j) {
+    if (!ctl.stall) return false;
+    bool stalled = ctl.stall[e] != 0;
+    if (!stalled && ctl.expected_ties && p.tie_words[e] != ctl.expected_ties[e]) stalled = true;
+    if (!stalled && ctl.move_limit && ctl.move_index >= ctl.move_limit[e]) stalled = true;
+    if (stalled && j == 0) {
+        ctl.stall[e] = 1;
+        if (ctl.actions) ctl.actions[e] = -1;
+    }
+    return stalled;
+}
+
+// SelfPlay.select_action (self_play.py:223-246) on the device copy of the stream, for the temperatures
+// whose arithmetic is exact everywhere: 0 (arg-max), 1 (visits ** 1.0 == visits; normalise, cumulative
+// sum, one legacy double, right-bisect -- RandomState.choice(p=...)) and inf (choice without p).
+// Returns the chosen child slot, or -2 for a temperature the host must handle (pow()).
+template <typename VisitOf>
+__device__ __forceinline__ int device_select_action(VisitOf visit_of, int n, double temperature, uint32_t* key,
+                                                    int32_t* pos, uint32_t* words) {
+    if (temperature == 0.0) {
+        int best = 0, best_v = visit_of(0);
+        for (int i = 1; i < n; ++i) {
+            const int v = visit_of(i);
+            if (v > best_v) {
+                best_v = v;
+                best = i;
+            }
+        }
+        return best;
+    }
+    if (isinf(temperature)) return static_cast<int>(mt_below(key, pos, static_cast<uint32_t>(n), words));
+    if (temperature != 1.0) return -2;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total = total + static_cast<double>(visit_of(i));
+    double total_p = 0.0;
+    for (int i = 0; i < n; ++i) total_p += static_cast<double>(visit_of(i)) / total;
+    const int32_t a = static_cast<int32_t>(mt_next(key, pos) >> 5);
+    const int32_t b = static_cast<int32_t>(mt_next(key, pos) >> 6);
+    *words += 2u;
+    const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+    double run = 0.0;
+    int idx = 0;
+    for (; idx < n; ++idx) {
+        run += static_cast<double>(visit_of(idx)) / total;
+        if (!(run / total_p <= u)) break;
+    }
+    return idx;
+}
+
 // Launch with optional HIP events bound to the dispatch itself (hipExtLaunchKernel records the
 // kernel's own start / end timestamps into the events, so profiling-mode timings are kernel
 // durations, comparable with rocprofv3's, not launch-to-launch gaps).

@@ -325,8 +325,7 @@ template <int G, int CH>
 __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p, FcNet net, FusedLayout lay,
                                                                    const float* __restrict__ weights,
                                                                    const float* __restrict__ observations,  // [E][obs]
-                                                                   const double* __restrict__ noise,        // [E][A] or null
-                                                                   const uint32_t* __restrict__ rng_skip, int n_sims) {
+                                                                   MoveCtl ctl, int n_sims) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     MZ_STAMP_DECL
     double* pbc_table = reinterpret_cast<double*>(smem);
@@ -347,8 +346,13 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
     const int group_base = threadIdx.x - j;
     if (e >= p.E) return;
     const int n_root = p.root_children[e];
-    if (j == 0) reset_search_state(p, e, rng_skip);
-    if (n_root == 0) return;
+    if (move_stalled(p, ctl, e, j)) return;
+    const double* noise = ctl.noise;
+    if (j == 0) reset_search_state(p, e, ctl.rng_skip);
+    if (n_root == 0) {
+        if (j == 0 && ctl.actions) ctl.actions[e] = -1;
+        return;
+    }
 
     uint8_t* region = smem + lay.off_trees + static_cast<size_t>(tree_in_block) * lay.tree_bytes;
     const LdsTree tree{region, p.block_stride, p.links_offset, reinterpret_cast<int32_t*>(region + lay.off_path)};
@@ -473,11 +477,25 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         p.min_max[e] = mm;
         p.max_depth[e] = max_depth;
         p.depth_sum[e] = depth_sum;
-        if (words) {
-            p.mt_pos[e] = mt_pos;
-            p.tie_words[e] = words;
+        uint32_t sample_words = 0;
+        if (ctl.temperature) {  // SelfPlay.select_action on the tree's own stream (kernel_common.h)
+            const ChildLinks* root_links = tree.links(0);
+            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, ctl.temperature[e],
+                                                  mt_key, &mt_pos, &sample_words);
+            if (ctl.actions) ctl.actions[e] = slot >= 0 ? p.root_action[static_cast<size_t>(e) * p.A + slot] : slot;
         }
+        if (words | sample_words) p.mt_pos[e] = mt_pos;
+        if (words) p.tie_words[e] = words;
+        if (ctl.tie_words) ctl.tie_words[e] = words;
+        if (ctl.sample_words) ctl.sample_words[e] = sample_words;
+        if (ctl.root_value_sum) ctl.root_value_sum[e] = root_value_sum;
+        if (ctl.root_predicted) ctl.root_predicted[e] = predicted;
+        if (ctl.max_depth) ctl.max_depth[e] = max_depth;
+        if (ctl.depth_sum) ctl.depth_sum[e] = static_cast<int32_t>(depth_sum);
     }
+    if (ctl.visits)
+        for (int c = j; c < p.A; c += G)
+            ctl.visits[static_cast<size_t>(e) * p.A + c] = (c < n_root) ? tree.links(0)[c].visits : 0;
     const int block_words = static_cast<int>(p.block_stride / 16);
     for (int k = 0; k <= n_sims; ++k) {
         const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
@@ -676,8 +694,8 @@ bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_i
 }
 
 hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
-                                  const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
-                                  hipStream_t stream, const LaunchTiming* timing) {
+                                  const float* observations, const MoveCtl& ctl, int n_sims, hipStream_t stream,
+                                  const LaunchTiming* timing) {
     const int grid = tree_grid(p);
     hipError_t attr_err = hipSuccess;
     dispatch_group(p, [&](auto g, auto ch) {
@@ -688,7 +706,7 @@ hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const F
                                        static_cast<int>(lay.total_bytes));
         if (attr_err != hipSuccess) return;
         launch_kernel(kernel, dim3(grid), dim3(kThreads), lay.total_bytes, stream, timing, p, net, lay, weights,
-                      observations, noise, rng_skip, n_sims);
+                      observations, ctl, n_sims);
     });
     if (attr_err != hipSuccess) return attr_err;
     return hipGetLastError();

@@ -22,6 +22,7 @@
 
 #include "../../include/mzmcts.h"
 #include "fc_net_device.h"
+#include "kernel_common.h"
 #include "narrow_device.h"
 #include "np_legacy_rng.h"
 #include "tree_layout.h"
@@ -36,14 +37,14 @@ bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_i
 bool narrow_supported(const TreeParams& p, const FcNet& net);
 bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit, NarrowLayout* out);
 hipError_t launch_search_fused_narrow(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
-                                      const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
-                                      int publish_tree, hipStream_t stream, const LaunchTiming* timing);
+                                      const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
+                                      hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_fc_inference_narrow(const TreeParams& p, const FcNet& net, const float* weights, bool initial,
                                       const float* in, const int64_t* action, float* value_logits, float* reward_logits,
                                       float* policy_logits, float* hidden_out, hipStream_t stream);
 hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
-                                  const float* observations, const double* noise, const uint32_t* rng_skip, int n_sims,
-                                  hipStream_t stream, const LaunchTiming* timing);
+                                  const float* observations, const MoveCtl& ctl, int n_sims, hipStream_t stream,
+                                  const LaunchTiming* timing);
 hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
                          const LaunchTiming* timing);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -61,6 +62,7 @@ hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* see
 #ifdef MZ_STAMPS
 namespace mz {
 hipError_t read_stamp_sums(unsigned long long* out, bool reset);
+hipError_t read_stamp_sums_narrow(unsigned long long* out, bool reset);
 }
 #endif
 
@@ -229,6 +231,31 @@ struct mzmcts_engine {
     uint8_t* d_download = nullptr;
     size_t download_bytes = 0;
     bool tie_words_applied = false;
+
+    // batch of moves queued back to back (mzmcts_moves_*)
+    struct MoveRecord {
+        int32_t pos, has_gauss;
+        double gauss;
+        uint64_t words;
+    };
+    struct MoveBatch {
+        int capacity = 0, n_moves = 0, enqueued = 0;
+        bool prepared = false, add_noise = false;
+        size_t out_stride = 0;  // bytes of one move's output block
+        size_t o_actions = 0, o_visits = 0, o_rvs = 0, o_pred = 0, o_depth = 0, o_ties = 0, o_sample = 0, o_dsum = 0;
+        uint8_t *h_in = nullptr, *d_in = nullptr;    // [noise M*E*A f64 | skip M*E u32 | temperature E f64 | limit E i32 | expected ties E u32]
+        size_t in_bytes = 0, o_skip = 0, o_temp = 0, o_limit = 0, o_expect = 0;
+        uint8_t *h_out = nullptr, *d_out = nullptr;  // [M] output blocks
+        uint8_t* d_stall = nullptr;
+        std::vector<MoveRecord> start;               // [E] mirror state when the batch was prepared
+        std::vector<uint32_t> start_lag;             // [E]
+        std::vector<MoveRecord> rec;                 // [M][E] mirror state right after move m's noise was drawn
+        std::vector<uint8_t> env_twisted;            // [E]
+        std::vector<uint64_t> twist_words;           // [E] word count at the first regeneration of this batch
+        std::vector<uint32_t> twist_keys;            // [E][624], rows valid where env_twisted
+        std::vector<double> temperature;             // [E]
+        hipEvent_t done = nullptr;
+    } batch;
 
     // pending asynchronous readout (mzmcts_readout_begin)
     hipEvent_t readout_event = nullptr;
@@ -1097,38 +1124,305 @@ int64_t mzmcts_fused_lds_bytes(mzmcts_engine* eng, int32_t hidden_in_lds) {
     return lay.total_bytes;
 }
 
+// One whole-move kernel (narrow or generic, see use_narrow) with the given per-move control block.
+static int launch_fused_move(mzmcts_engine* eng, const float* observations, const mz::MoveCtl& ctl, bool hidden_in_lds,
+                             hipStream_t stream) {
+    if (use_narrow(eng)) {
+        mz::NarrowLayout nl{};
+        mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
+        ProfScope scope(eng, stream, kProfFused);
+        MZ_HIP(eng, mz::launch_search_fused_narrow(eng->p, eng->fc, nl, eng->fc_weights, observations, ctl, eng->p.S,
+                                                   eng->publish_tree ? 1 : 0, stream, scope.get()));
+        eng->tree_published = eng->publish_tree;
+    } else {
+        mz::FusedLayout lay{};
+        if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds, kLdsPerWorkgroup, &lay))
+            return fail(eng, MZMCTS_ERR_INVALID, "fused search: the trees of one workgroup do not fit in 160 KB of LDS (use a "
+                                                 "wider group_width or the lock-step path)");
+        ProfScope scope(eng, stream, kProfFused);
+        MZ_HIP(eng, mz::launch_search_fused_fc(eng->p, eng->fc, lay, eng->fc_weights, observations, ctl, eng->p.S, stream,
+                                               scope.get()));
+        eng->tree_published = true;
+    }
+    return MZMCTS_OK;
+}
+
 int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_t hidden_in_lds, void* stream_) {
     if (!eng || !observations) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: call mzmcts_fc_configure first");
     if (!eng->search_begun) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc called before begin_search");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const double* noise = eng->noise_this_search ? eng->d_noise : nullptr;
-    if (use_narrow(eng)) {
-        mz::NarrowLayout nl{};
-        mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
-        ProfScope scope(eng, stream, kProfFused);
-        MZ_HIP(eng, mz::launch_search_fused_narrow(eng->p, eng->fc, nl, eng->fc_weights, observations, noise, eng->d_skip,
-                                                   eng->p.S, eng->publish_tree ? 1 : 0, stream, scope.get()));
-        eng->tree_published = eng->publish_tree;
-    } else {
-        mz::FusedLayout lay{};
-        if (!mz::plan_fused_layout(eng->p, eng->fc, hidden_in_lds != 0, kLdsPerWorkgroup, &lay))
-            return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: the trees of one workgroup do not fit in 160 KB of "
-                                                 "LDS (use a wider group_width or the lock-step path)");
-        ProfScope scope(eng, stream, kProfFused);
-        MZ_HIP(eng, mz::launch_search_fused_fc(eng->p, eng->fc, lay, eng->fc_weights, observations, noise, eng->d_skip,
-                                               eng->p.S, stream, scope.get()));
-        eng->tree_published = true;
-    }
+    mz::MoveCtl ctl{};
+    ctl.noise = eng->noise_this_search ? eng->d_noise : nullptr;
+    ctl.rng_skip = eng->d_skip;
+    int rc = launch_fused_move(eng, observations, ctl, hidden_in_lds != 0, stream);
+    if (rc) return rc;
     eng->roots_ready = true;
     eng->sim = eng->p.S;
+    return MZMCTS_OK;
+}
+
+
+// ---- batches of moves without host round trips ---------------------------------------------------------------
+// Stream bookkeeping.  Per env the numpy stream is consumed, move after move, as
+//     [Dirichlet(m)] [tie-breaks of search m] [select_action(m)]      (self_play.py:303-315, 372-378, 223-246)
+// The host draws every Dirichlet row of the batch up front on its mirror, assuming search m spends one word on
+// the unavoidable first-simulation tie (none with a single legal action) and select_action consumes what the
+// temperature implies (0 words at T = 0, 2 at T = 1); the kernels consume the tie-break and sampling words on
+// the device copy and skip the Dirichlet words (rng_skip ring).  An env whose search spent a different number
+// of tie-break words stalls from the next move on (kernel_common.h); collect() puts the mirror back to the
+// state recorded after the last noise row that was really used and replays what the device consumed.
+static void restore_stream(mzmcts_engine* eng, int e, const mzmcts_engine::MoveRecord& r) {
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    mz::HostStream& s = eng->streams[e];
+    s.pos = r.pos;
+    s.words = r.words;
+    if (b.env_twisted[e]) {
+        // the block was regenerated somewhere in the batch: start from the copy taken just before, then walk forward
+        std::memcpy(s.key, b.twist_keys.data() + static_cast<size_t>(e) * mz::kMtN, sizeof(s.key));
+        if (r.words >= b.twist_words[e]) {
+            s.pos = mz::kMtN;
+            s.words = b.twist_words[e];
+            s.skip(r.words - b.twist_words[e]);
+        }
+    }
+    s.has_gauss = r.has_gauss;
+    s.gauss = r.gauss;
+}
+
+static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (n_moves <= b.capacity) return 0;
+    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A), M = static_cast<size_t>(n_moves);
+    auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+    b.o_skip = align(sizeof(double) * M * E * A);
+    b.o_temp = align(b.o_skip + sizeof(uint32_t) * M * E);
+    b.o_limit = align(b.o_temp + sizeof(double) * E);
+    b.o_expect = align(b.o_limit + sizeof(int32_t) * E);
+    b.in_bytes = align(b.o_expect + sizeof(uint32_t) * E);
+    b.o_actions = 0;
+    b.o_visits = align(sizeof(int32_t) * E);
+    b.o_rvs = align(b.o_visits + sizeof(int32_t) * E * A);
+    b.o_pred = align(b.o_rvs + sizeof(double) * E);
+    b.o_depth = align(b.o_pred + sizeof(float) * E);
+    b.o_ties = align(b.o_depth + sizeof(int32_t) * E);
+    b.o_sample = align(b.o_ties + sizeof(uint32_t) * E);
+    b.o_dsum = align(b.o_sample + sizeof(uint32_t) * E);
+    b.out_stride = align(b.o_dsum + sizeof(int32_t) * E);
+    int rc;  // (earlier, smaller buffers stay registered with the engine and are freed with it)
+    if ((rc = dev_alloc(eng, &b.d_in, b.in_bytes))) return rc;
+    if ((rc = pinned_alloc(eng, &b.h_in, b.in_bytes))) return rc;
+    if ((rc = dev_alloc(eng, &b.d_out, b.out_stride * M))) return rc;
+    if ((rc = pinned_alloc(eng, &b.h_out, b.out_stride * M))) return rc;
+    if (!b.d_stall && (rc = dev_alloc(eng, &b.d_stall, E))) return rc;
+    if (!b.done) MZ_HIP(eng, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    b.rec.resize(M * E);
+    b.start.resize(E);
+    b.start_lag.assign(E, 0);
+    b.env_twisted.assign(E, 0);
+    b.twist_words.assign(E, 0);
+    b.twist_keys.resize(E * mz::kMtN);
+    b.temperature.assign(E, 0.0);
+    b.capacity = n_moves;
+    return 0;
+}
+
+int mzmcts_moves_prepare(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
+                         const int32_t* to_play, int32_t add_noise, const double* temperature, void* stream_) {
+    if (!eng || !legal || !num_legal || !to_play || !temperature)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: null argument");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: call mzmcts_fc_configure first");
+    if (n_moves < 1 || n_moves > 4096) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: n_moves out of range");
+    if (eng->batch.prepared) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: collect the previous batch first");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int E = eng->p.E, A = eng->p.A;
+    for (int e = 0; e < E; ++e) {
+        const int n = num_legal[e];
+        if (n < 0 || n > A)
+            return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
+        for (int i = 0; i < n; ++i) {
+            const int a = legal[static_cast<size_t>(e) * A + i];
+            if (a < 0 || a >= A)
+                return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
+        }
+        const double t = temperature[e];
+        if (!(t == 0.0 || t == 1.0 || std::isinf(t)))
+            return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: the device samples actions at temperature 0, 1 or inf "
+                                                 "only (visit_count ** (1 / T) needs the host's pow)");
+    }
+    int rc = ensure_batch_capacity(eng, n_moves);
+    if (rc) return rc;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    std::memcpy(eng->h_legal, legal, sizeof(int32_t) * static_cast<size_t>(E) * A);
+    std::memcpy(eng->h_nlegal, num_legal, sizeof(int32_t) * E);
+    std::memcpy(eng->h_to_play, to_play, sizeof(int32_t) * E);
+    double* h_noise = reinterpret_cast<double*>(b.h_in);
+    uint32_t* h_skip = reinterpret_cast<uint32_t*>(b.h_in + b.o_skip);
+    double* h_temp = reinterpret_cast<double*>(b.h_in + b.o_temp);
+    int32_t* h_limit = reinterpret_cast<int32_t*>(b.h_in + b.o_limit);
+    uint32_t* h_expect = reinterpret_cast<uint32_t*>(b.h_in + b.o_expect);
+    const double alpha = eng->cfg.root_dirichlet_alpha;
+    const size_t EA = static_cast<size_t>(E) * A;
+    eng->for_each_env([&](int lo, int hi) {
+        for (int e = lo; e < hi; ++e) {
+            const int n = eng->h_nlegal[e];
+            const double t = temperature[e];
+            h_temp[e] = t;
+            b.temperature[e] = t;
+            b.env_twisted[e] = 0;
+            // words select_action will consume on the device; inf draws a bounded integer (rejection: unknown count)
+            const int assumed = (t == 0.0) ? 0 : (t == 1.0 ? 2 : -1);
+            h_limit[e] = (n == 0) ? 0 : (assumed < 0 ? 1 : n_moves);
+            // The first simulation always ties: the root has no visits yet, so every child scores 0
+            // (sqrt(0) in ucb_score, self_play.py:385-390) and select_child draws numpy.random.choice over all n
+            // of them -- one masked 32-bit word when n is a power of two, a rejection loop otherwise (one word is
+            // the likeliest outcome and the one assumed).  Later ties need exactly equal fp64 scores.
+            const uint32_t tie_words = n > 1 ? 1u : 0u;
+            h_expect[e] = tie_words;
+            mz::HostStream& s = eng->streams[e];
+            b.start[e] = mzmcts_engine::MoveRecord{s.pos, s.has_gauss, s.gauss, s.words};
+            b.start_lag[e] = eng->lag[e];
+            s.twist_backup = b.twist_keys.data() + static_cast<size_t>(e) * mz::kMtN;
+            s.twisted = false;
+            for (int m = 0; m < n_moves; ++m) {
+                double* row = h_noise + static_cast<size_t>(m) * EA + static_cast<size_t>(e) * A;
+                for (int i = 0; i < A; ++i) row[i] = 0.0;
+                uint32_t skip = 0;
+                if (n > 0 && m < h_limit[e]) {
+                    if (m > 0) s.skip(static_cast<uint64_t>(tie_words) + static_cast<uint64_t>(assumed));
+                    const uint64_t before = s.words;
+                    if (add_noise) s.dirichlet(alpha, n, row);
+                    skip = static_cast<uint32_t>(s.words - before) + (m == 0 ? eng->lag[e] : 0u);
+                }
+                h_skip[static_cast<size_t>(m) * E + e] = skip;
+                b.rec[static_cast<size_t>(m) * E + e] = mzmcts_engine::MoveRecord{s.pos, s.has_gauss, s.gauss, s.words};
+            }
+            if (n > 0) eng->lag[e] = 0;
+            b.env_twisted[e] = s.twisted ? 1 : 0;
+            b.twist_words[e] = s.twist_words;
+            s.twist_backup = nullptr;
+            s.twisted = false;
+        }
+    });
+    MZ_HIP(eng, hipMemcpyAsync(eng->d_upload, eng->h_upload, eng->upload_bytes_no_noise, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemcpyAsync(b.d_in, b.h_in, b.in_bytes, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemsetAsync(b.d_stall, 0, static_cast<size_t>(E), stream));
+    b.n_moves = n_moves;
+    b.enqueued = 0;
+    b.add_noise = add_noise != 0;
+    b.prepared = true;
+    eng->search_begun = false;
+    eng->roots_ready = false;
+    eng->have_readout = false;
+    return MZMCTS_OK;
+}
+
+int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* stream_) {
+    if (!eng || !observations) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: null argument");
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.prepared || b.enqueued >= b.n_moves)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: no prepared move left in the batch");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A);
+    const int m = b.enqueued;
+    uint8_t* out = b.d_out + b.out_stride * static_cast<size_t>(m);
+    mz::MoveCtl ctl{};
+    ctl.noise = b.add_noise ? reinterpret_cast<const double*>(b.d_in) + static_cast<size_t>(m) * E * A : nullptr;
+    ctl.rng_skip = reinterpret_cast<const uint32_t*>(b.d_in + b.o_skip) + static_cast<size_t>(m) * E;
+    ctl.temperature = reinterpret_cast<const double*>(b.d_in + b.o_temp);
+    ctl.move_limit = reinterpret_cast<const int32_t*>(b.d_in + b.o_limit);
+    ctl.stall = b.d_stall;
+    ctl.move_index = m;
+    ctl.expected_ties = m > 0 ? reinterpret_cast<const uint32_t*>(b.d_in + b.o_expect) : nullptr;
+    ctl.actions = reinterpret_cast<int32_t*>(out + b.o_actions);
+    ctl.visits = reinterpret_cast<int32_t*>(out + b.o_visits);
+    ctl.root_value_sum = reinterpret_cast<double*>(out + b.o_rvs);
+    ctl.root_predicted = reinterpret_cast<float*>(out + b.o_pred);
+    ctl.max_depth = reinterpret_cast<int32_t*>(out + b.o_depth);
+    ctl.tie_words = reinterpret_cast<uint32_t*>(out + b.o_ties);
+    ctl.sample_words = reinterpret_cast<uint32_t*>(out + b.o_sample);
+    ctl.depth_sum = reinterpret_cast<int32_t*>(out + b.o_dsum);
+    int rc = launch_fused_move(eng, observations, ctl, true, stream);
+    if (rc) return rc;
+    b.enqueued = m + 1;
+    return MZMCTS_OK;
+}
+
+const int32_t* mzmcts_moves_actions(mzmcts_engine* eng, int32_t move) {
+    if (!eng || !eng->batch.prepared || move < 0 || move >= eng->batch.n_moves) return nullptr;
+    return reinterpret_cast<const int32_t*>(eng->batch.d_out + eng->batch.out_stride * static_cast<size_t>(move) +
+                                            eng->batch.o_actions);
+}
+
+int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actions, int32_t* visits, double* root_value_sum,
+                         float* root_predicted, int32_t* max_depth, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.prepared) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_collect: no batch in flight");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int E = eng->p.E, A = eng->p.A, M = b.enqueued;
+    if (M > 0) MZ_HIP(eng, hipMemcpyAsync(b.h_out, b.d_out, b.out_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, eng->p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipEventRecord(b.done, stream));
+    MZ_HIP(eng, hipEventSynchronize(b.done));
+    b.prepared = false;
+    if (eng->h_error_flag[0] != 0)
+        return fail(eng, MZMCTS_ERR_INVALID, (eng->h_error_flag[0] & 8) ? "device error flag set: unexpected DPP lane mapping"
+                                             : (eng->h_error_flag[0] & 2)
+                                                 ? "device error flag set: tree links are inconsistent"
+                                                 : "device error flag set: a UCB score was NaN (no maximum to select)");
+    auto block = [&](int m, size_t off) { return b.h_out + b.out_stride * static_cast<size_t>(m) + off; };
+    std::atomic<int64_t> played_total{0}, depth_total{0};
+    eng->for_each_env([&](int lo, int hi) {
+        int64_t local = 0, local_depth = 0;
+        for (int e = lo; e < hi; ++e) {
+            int k = 0;  // moves of this env that were searched: the first k of the batch
+            if (eng->h_nlegal[e] > 0)
+                while (k < M && reinterpret_cast<const int32_t*>(block(k, b.o_actions))[e] >= 0) ++k;
+            if (moves_done) moves_done[e] = k;
+            for (int m = 0; m < M; ++m) {
+                const bool live = m < k;
+                const size_t me = static_cast<size_t>(m) * E + e;
+                if (actions) actions[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_actions))[e] : -1;
+                if (visits)
+                    for (int i = 0; i < A; ++i)
+                        visits[me * A + i] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_visits))[static_cast<size_t>(e) * A + i] : 0;
+                if (root_value_sum) root_value_sum[me] = live ? reinterpret_cast<const double*>(block(m, b.o_rvs))[e] : 0.0;
+                if (root_predicted) root_predicted[me] = live ? reinterpret_cast<const float*>(block(m, b.o_pred))[e] : 0.f;
+                if (max_depth) max_depth[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_depth))[e] : 0;
+                if (live) local_depth += reinterpret_cast<const int32_t*>(block(m, b.o_dsum))[e];
+            }
+            if (eng->h_nlegal[e] == 0) continue;
+            local += k;
+            // the mirror ran ahead over the whole batch: put it where the device copy really is
+            mz::HostStream& s = eng->streams[e];
+            if (k == 0) {  // nothing was searched (batch collected before its first move ran): undo every draw
+                restore_stream(eng, e, b.start[e]);
+                eng->lag[e] = b.start_lag[e];
+                continue;
+            }
+            const mzmcts_engine::MoveRecord& r = b.rec[static_cast<size_t>(k - 1) * E + e];
+            if (s.words != r.words) restore_stream(eng, e, r);
+            s.skip(reinterpret_cast<const uint32_t*>(block(k - 1, b.o_ties))[e]);
+            s.skip(reinterpret_cast<const uint32_t*>(block(k - 1, b.o_sample))[e]);
+            eng->lag[e] = 0;
+        }
+        played_total.fetch_add(local, std::memory_order_relaxed);
+        depth_total.fetch_add(local_depth, std::memory_order_relaxed);
+    });
+    eng->prof.simulations += played_total.load() * eng->p.S;
+    eng->prof.select_depth_sum += depth_total.load();
     return MZMCTS_OK;
 }
 
 #ifdef MZ_STAMPS
 // diagnostic build only: per-phase cycle sums of the fused kernel (see tools/stamp_fused.py)
 int mzmcts_debug_read_stamps(unsigned long long* out, int32_t reset) {
-    return mz::read_stamp_sums(out, reset != 0) == hipSuccess ? 0 : -2;
+    unsigned long long narrow[16];
+    if (mz::read_stamp_sums(out, reset != 0) != hipSuccess || mz::read_stamp_sums_narrow(narrow, reset != 0) != hipSuccess)
+        return -2;
+    for (int i = 0; i < 16; ++i) out[i] += narrow[i];
+    return 0;
 }
 #endif
 

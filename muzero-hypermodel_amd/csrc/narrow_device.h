@@ -51,7 +51,7 @@ struct NarrowLayout {
     uint32_t off_bias;     // float[kNarrowUnits][16]
     uint32_t off_trees;
     uint32_t tree_bytes;
-    uint32_t off_vterm;    // within a tree region: double[(S+1)][A]
+    uint32_t off_vterm;    // within a tree region: double[(S+1)][pow2 >= A]
     uint32_t off_path;     // int32[S]
     uint32_t off_hidden;   // float[(S+1)][enc]
     uint32_t off_misc;     // int32[16] root actions | float[16] root policy logits
@@ -142,29 +142,38 @@ __device__ __forceinline__ void stage_narrow_units(const FcNet& net, const float
     }
 }
 
-// bias + W x for this lane's neuron of unit U; x holds the layer input, element k in lane k (0 beyond it)
+// bias + W x for this lane's neuron of unit U; x holds the layer input, element k in lane k (0 beyond it).
+// Sixteen v_fmac_f32 whose activation operand carries the DPP row rotate, written out because the compiler
+// will not fold a DPP move into the tied-accumulator form (it emits mov_dpp + fmac + hazard nops: 2.4x the
+// issue slots).  Two accumulators halve the dependent chain.  Hazards the assembler cannot see inside the
+// block: a VALU write of x (or of EXEC) immediately before the first DPP read -- covered by the leading nop.
 template <int U>
 __device__ __forceinline__ float narrow_unit(const float4* units, const float* bias, float x, int j) {
     const float4* w = units + (U * 4) * kRow + j;
     const float4 w0 = w[0], w1 = w[kRow], w2 = w[2 * kRow], w3 = w[3 * kRow];
     float a = bias[U * kRow + j];
     float b = 0.f;
-    a = fmaf(row_ror<0>(x), w0.x, a);
-    b = fmaf(row_ror<1>(x), w0.y, b);
-    a = fmaf(row_ror<2>(x), w0.z, a);
-    b = fmaf(row_ror<3>(x), w0.w, b);
-    a = fmaf(row_ror<4>(x), w1.x, a);
-    b = fmaf(row_ror<5>(x), w1.y, b);
-    a = fmaf(row_ror<6>(x), w1.z, a);
-    b = fmaf(row_ror<7>(x), w1.w, b);
-    a = fmaf(row_ror<8>(x), w2.x, a);
-    b = fmaf(row_ror<9>(x), w2.y, b);
-    a = fmaf(row_ror<10>(x), w2.z, a);
-    b = fmaf(row_ror<11>(x), w2.w, b);
-    a = fmaf(row_ror<12>(x), w3.x, a);
-    b = fmaf(row_ror<13>(x), w3.y, b);
-    a = fmaf(row_ror<14>(x), w3.z, a);
-    b = fmaf(row_ror<15>(x), w3.w, b);
+    asm volatile(
+        "s_nop 4\n\t"
+        "v_fmac_f32_e32 %0, %2, %3\n\t"
+        "v_fmac_f32_dpp %1, %2, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %5 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %6 row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %7 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %8 row_ror:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %9 row_ror:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %10 row_ror:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %12 row_ror:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %13 row_ror:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %14 row_ror:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %15 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %16 row_ror:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %17 row_ror:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %2, %18 row_ror:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(a), "+v"(b)
+        : "v"(x), "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x),
+          "v"(w2.y), "v"(w2.z), "v"(w2.w), "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w));
     return a + b;
 }
 
@@ -264,16 +273,17 @@ struct LdsTreeV {
     uint8_t* blocks;
     uint32_t block_stride;
     uint32_t links_offset;
-    double* vterm_base;   // [(S+1)][A]
+    double* vterm_base;   // [(S+1)][1 << vterm_shift], 1 << vterm_shift = pow2 >= A
     int32_t* path;
-    int A;
+    int vterm_shift;
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): k <= S < 2^15, strides < 2^13
     __device__ __forceinline__ ChildStats* stats(int k) const {
-        return reinterpret_cast<ChildStats*>(blocks + static_cast<uint32_t>(k) * block_stride);
+        return reinterpret_cast<ChildStats*>(blocks + __umul24(static_cast<uint32_t>(k), block_stride));
     }
     __device__ __forceinline__ ChildLinks* links(int k) const {
-        return reinterpret_cast<ChildLinks*>(blocks + static_cast<uint32_t>(k) * block_stride + links_offset);
+        return reinterpret_cast<ChildLinks*>(blocks + __umul24(static_cast<uint32_t>(k), block_stride) + links_offset);
     }
-    __device__ __forceinline__ double* vterm(int k) const { return vterm_base + k * A; }
+    __device__ __forceinline__ double* vterm(int k) const { return vterm_base + (k << vterm_shift); }
     __device__ __forceinline__ void path_store(int level, int packed) const { path[level] = packed; }
     __device__ __forceinline__ int path_load(int level) const { return path[level]; }
 };
@@ -283,11 +293,28 @@ struct LdsTreeV {
 //   prior_score = ((log(..)+init) * (sqrt(N)/(n+1))) * prior      table entry [N][n] (same two IEEE ops)
 //   value_score = normalize(vterm)                                  vterm = r + discount*(+-Q), stored by the backup
 // Scores, tie lists and RNG draws are those of tree_device.h's descend(), bit for bit.
+// Diagnostic build (-DMZ_STAMPS): the descent's inner phases go to slots 8..11 of the caller's stamp
+// accumulators; outstanding LDS reads are made to land first so a phase is charged with its own waiting.
+#ifdef MZ_STAMPS
+#define MZ_DSTAMP_PARAMS , unsigned long long* dstamp_acc, unsigned long long& dstamp_prev
+#define MZ_DSTAMP_ARGS , stamp_acc, stamp_prev
+#define MZ_DSTAMP(slot)                                                \
+    do {                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+        const unsigned long long now__ = __builtin_readcyclecounter(); \
+        dstamp_acc[slot] += now__ - dstamp_prev;                       \
+        dstamp_prev = now__;                                           \
+    } while (0)
+#else
+#define MZ_DSTAMP_PARAMS
+#define MZ_DSTAMP_ARGS
+#define MZ_DSTAMP(slot)
+#endif
 template <int SPAN, bool PBC2>
 __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
                                                int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
                                                int32_t& mt_pos, uint32_t& words, int j, int group_base,
-                                               int32_t* error_flag) {
+                                               int32_t* error_flag MZ_DSTAMP_PARAMS) {
     const bool has_range = mm.maximum > mm.minimum;
     const double range = mm.maximum - mm.minimum;
     int n_children = n_root_children;
@@ -301,17 +328,21 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
         const int visits = lk->visits;
         const int child = lk->child_node;
         const double vt = acc.vterm(k)[c];
+        MZ_DSTAMP(8);
         double pb;
         if constexpr (PBC2) {
-            pb = pbc2[((N * (N + 1)) >> 1) + visits];
+            pb = pbc2[(__mul24(N, N + 1) >> 1) + visits];
         } else {
             pb = pbc[N];
             pb = pb * (pbc[S + 1 + N] / static_cast<double>(visits + 1));
         }
         const double prior_score = pb * prior;
-        const double normalized = (vt - mm.minimum) / range;  // discarded unless visited and max > min
+        double normalized = (vt - mm.minimum) / range;  // discarded unless visited and max > min
+        // keep the load and the division out of a `visits > 0` branch: they must not wait for the visit count
+        asm volatile("" : "+v"(normalized));
         const double value_score = visits > 0 ? (has_range ? normalized : vt) : 0.0;
         const double score = valid ? prior_score + value_score : -INFINITY;
+        MZ_DSTAMP(9);
         double best = score;
         MZ_BUTTERFLY(SPAN, SPAN, best = fmax(best, partner<M>(best)));
 
@@ -329,6 +360,7 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
             mask = 1u;
         }
         slot = __ffs(static_cast<int>(mask)) - 1;
+        MZ_DSTAMP(10);
         const int packed = row_or((j == slot) ? (visits | ((child + 1) << 16)) : 0);
         const int sel_visits = packed & 0xffff;
         const int sel_child = (packed >> 16) - 1;
@@ -342,6 +374,7 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
         k = sel_child;
         N = sel_visits;
         n_children = A;
+        MZ_DSTAMP(11);
     }
     return Descent{depth, k, slot};
 }

@@ -100,6 +100,12 @@ struct HostStream {
     int32_t has_gauss = 0;
     double gauss = 0.0;
     uint64_t words = 0;  // 32-bit words drawn since construction / seeding
+    // Speculative draws (mzmcts_moves_prepare) must be undoable: while `twist_backup` is set, the block of
+    // 624 words is copied there the first time it is about to be regenerated (with the word count at that
+    // moment), which is all a later restore to ANY earlier or later position needs.
+    uint32_t* twist_backup = nullptr;
+    bool twisted = false;
+    uint64_t twist_words = 0;
 
     void seed(uint32_t s) {
         mt_seed(key, &pos, s);
@@ -108,6 +114,11 @@ struct HostStream {
         words = 0;
     }
     uint32_t u32() {
+        if (pos == kMtN && twist_backup && !twisted) {
+            std::memcpy(twist_backup, key, sizeof(key));
+            twisted = true;
+            twist_words = words;
+        }
         ++words;
         return mt_next(key, &pos);
     }

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _native
-from ._native import MzConfig, MzFcDesc, MzProfile, MzRootStats, c_f64_p, c_i32_p, c_i64_p, c_u32_p, ptr
+from ._native import MzConfig, MzFcDesc, MzProfile, MzRootStats, c_f32_p, c_f64_p, c_i32_p, c_i64_p, c_u32_p, ptr
 
 
 def hidden_state_shape(config):
@@ -396,6 +396,65 @@ class BatchedMCTS:
                                                      1 if self.fused_hidden_in_lds else 0, self._stream()))
         self._check(self._lib.mzmcts_readout_begin(self._h, self._stream()))
 
+    # ---- batches of moves without host round trips (include/mzmcts.h: mzmcts_moves_*) -------------------
+    def moves_prepare(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True, num_legal=None):
+        """Draw the exploration noise of the next `n_moves` moves and upload it; the legal action sets must stay
+        the same over the batch, temperature (scalar or [E]) must be 0, 1 or inf."""
+        if num_legal is not None:
+            self._legal[:] = legal_actions
+            self._nlegal[:] = num_legal
+        else:
+            self._legal[:] = 0
+            for e, legal in enumerate(legal_actions):
+                n = 0 if legal is None else len(legal)
+                if n > self.A:
+                    raise AssertionError("Legal actions should be a subset of the action space.")
+                self._nlegal[e] = n
+                if n:
+                    self._legal[e, :n] = legal
+        self._to_play[:] = to_play
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+        self._check(self._lib.mzmcts_moves_prepare(self._h, int(n_moves), self._p_legal, self._p_nlegal, self._p_to_play,
+                                                   1 if add_exploration_noise else 0, ptr(t, c_f64_p), self._stream()))
+        self._batch_moves = int(n_moves)
+        self._batch_keep = []
+
+    def moves_enqueue(self, observations):
+        """Queue the next search of the prepared batch; `observations`: resident fp32 CUDA tensor [E, obs]."""
+        assert observations.is_cuda and observations.dtype == torch.float32 and observations.is_contiguous()
+        assert observations.numel() == self.E * self._fc_obs_floats, "observation batch has the wrong size"
+        self._batch_keep.append(observations)
+        self._check(self._lib.mzmcts_moves_enqueue(self._h, observations.data_ptr(), self._stream()))
+
+    def moves_actions(self, move):
+        """Device tensor (int32 [E]) holding move `move`'s sampled actions once its search has run."""
+        addr = self._lib.mzmcts_moves_actions(self._h, int(move))
+        if not addr:
+            raise RuntimeError("no such move in the prepared batch")
+        return _device_view(addr, self.E, torch.int32, self.device)
+
+    def moves_collect(self):
+        """Wait for the queued searches.  Returns dict(moves_done [E], actions [M,E], visits [M,E,A],
+        root_value_sum [M,E], root_predicted [M,E], max_depth [M,E]); M = searches queued."""
+        M = len(self._batch_keep)
+        out = dict(moves_done=np.zeros(self.E, np.int32), actions=np.zeros((M, self.E), np.int32),
+                   visits=np.zeros((M, self.E, self.A), np.int32), root_value_sum=np.zeros((M, self.E)),
+                   root_predicted=np.zeros((M, self.E), np.float32), max_depth=np.zeros((M, self.E), np.int32))
+        self._check(self._lib.mzmcts_moves_collect(
+            self._h, ptr(out["moves_done"], c_i32_p), ptr(out["actions"], c_i32_p), ptr(out["visits"], c_i32_p),
+            ptr(out["root_value_sum"], c_f64_p), ptr(out["root_predicted"], c_f32_p), ptr(out["max_depth"], c_i32_p),
+            self._stream()))
+        self._batch_keep = []
+        return out
+
+    def run_moves(self, observations, legal_actions, to_play, temperature, add_exploration_noise=True, num_legal=None):
+        """`len(observations)` moves back to back (one resident observation tensor per move)."""
+        with torch.cuda.device(self.device):
+            self.moves_prepare(len(observations), legal_actions, to_play, temperature, add_exploration_noise, num_legal)
+            for obs in observations:
+                self.moves_enqueue(obs)
+            return self.moves_collect()
+
     @torch.no_grad()
     def search(self, model, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
         """MCTS.run for all envs.  observations: [E, C, H, W] (numpy or tensor)."""
@@ -456,6 +515,18 @@ class BatchedMCTS:
         select = mean_depth * (8 + 24 * A) + 2 * 4 * H
         backup = (mean_depth + 1) * (28 + two) + 32 + 24 * A + 13 + 4 * (A + 2 * F)
         return dict(select=select, expand_backup=backup, total=select + backup)
+
+
+def _device_view(address, numel, dtype, device):
+    """A torch tensor over device memory the library owns (no copy, no ownership)."""
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    typestr = {torch.int32: "<i4", torch.float32: "<f4", torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+
+    class _Span:
+        __cuda_array_interface__ = {"shape": (int(numel),), "typestr": typestr, "data": (int(address), False),
+                                    "version": 2, "strides": None}
+    assert itemsize * numel > 0
+    return torch.as_tensor(_Span(), device=device)
 
 
 class PipelinedSearch:

@@ -1,0 +1,112 @@
+"""Batches of moves queued back to back (mzmcts_moves_*): every move an env plays inside a batch must be
+bit-identical to the one-move-at-a-time path (fused search + host-side select_action on the mirror stream),
+whatever happens to the speculation the batch rests on (tie-breaks, unknown sampling word counts, MT19937
+block regenerations inside the pre-drawn stretch)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from parity_helpers import cartpole_model_and_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(pkg):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    return importlib.import_module("muzero-hypermodel_amd.engine")
+
+
+def cartpole_setup(pkg, ties):
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    config = importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
+    model, _ = cartpole_model_and_weights(models, config, "cuda")
+    if ties:   # all-equal priors below the root: the search breaks ties with the RNG all the time (fixture G5 recipe)
+        with torch.no_grad():
+            for name, prm in model.named_parameters():
+                if name.startswith("prediction_policy_network.module.2"):
+                    prm.zero_()
+    return config, model
+
+
+@pytest.mark.parametrize("group,variant,ties,temps,batch", [
+    (16, "narrow", False, "one", 6),
+    (16, "narrow", True, "one", 4),          # ties at every level: most envs stall after one move per batch
+    (16, "narrow", False, "mixed", 5),       # T = 0 / 1 / inf per env (inf: a single move per batch)
+    (4, "generic", False, "one", 3),
+    (4, "generic", True, "mixed", 3),
+])
+def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, temps, batch):
+    config, model = cartpole_setup(pkg, ties)
+    E, N = 83, 40 if ties else 24            # N moves per env: > 624 RNG words per env when ties abound
+    rs = np.random.RandomState(4)
+    obs = torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()   # same observation every move
+    legal = [[0, 1] if e % 11 else [] for e in range(E)]                                # a few inactive envs
+    to_play = [0] * E
+    T = np.ones(E) if temps == "one" else np.array([[0.0, 1.0, np.inf, 1.0][e % 4] for e in range(E)])
+    seeds = [1000 + e for e in range(E)]
+
+    ref = eng.BatchedMCTS(config, E, seeds=seeds, group_width=group)
+    ref.configure_fused_fc(model)
+    ref.set_fused_options(variant, publish_tree=False)
+    want = []
+    for _ in range(N):
+        st = ref.search_fused(obs, legal, to_play, True)
+        actions, _ = ref.sample_actions(T)
+        want.append((actions.copy(), st["visits"].copy(), st["root_value_sum"].copy(),
+                     st["root_predicted_value"].copy(), st["max_tree_depth"].copy()))
+    ref.close()
+
+    got = [[] for _ in range(E)]
+    engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=group)
+    engine.configure_fused_fc(model)
+    engine.set_fused_options(variant, publish_tree=False)
+    assert engine.fused_variant() == variant
+    rounds = 0
+    active = [e for e in range(E) if legal[e]]
+    while min(len(got[e]) for e in active) < N:
+        out = engine.run_moves([obs] * batch, legal, to_play, T, True)
+        rounds += 1
+        assert rounds <= 2 * N + 4
+        for e in range(E):
+            k = out["moves_done"][e]
+            assert (k >= 1) == bool(legal[e]) and (out["actions"][k:, e] == -1).all()
+            if np.isinf(T[e]) and legal[e]:
+                assert k == 1
+            for m in range(k):
+                got[e].append((out["actions"][m, e], out["visits"][m, e].copy(), out["root_value_sum"][m, e],
+                               out["root_predicted"][m, e], out["max_depth"][m, e]))
+    engine.close()
+    if ties:
+        assert rounds >= N // 2             # the tie-breaking searches really did stall the batches
+    else:
+        assert rounds <= (N // batch + 3) * (batch if temps == "mixed" else 1)
+    for e in active:
+        for i in range(N):
+            a, v, rv, pred, depth = got[e][i]
+            wa, wv, wrv, wpred, wdepth = want[i]
+            assert a == wa[e] and np.array_equal(v, wv[e]), (e, i)
+            assert rv == wrv[e] and np.float32(pred) == np.float32(wpred[e]) and depth == wdepth[e], (e, i)
+
+
+def test_move_batch_actions_are_on_the_device(eng, pkg):
+    config, model = cartpole_setup(pkg, False)
+    E = 256
+    obs = torch.from_numpy(np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()
+    engine = eng.BatchedMCTS(config, E, group_width=16)
+    engine.configure_fused_fc(model)
+    engine.set_fused_options("auto", publish_tree=False)
+    engine.moves_prepare(3, [[0, 1]] * E, [0] * E, 1.0)
+    for _ in range(3):
+        engine.moves_enqueue(obs)
+    on_device = [engine.moves_actions(m) for m in range(3)]
+    out = engine.moves_collect()
+    for m in range(3):
+        assert np.array_equal(on_device[m].cpu().numpy(), out["actions"][m])
+    with pytest.raises(RuntimeError):
+        engine.moves_collect()
+    with pytest.raises(RuntimeError, match="temperature 0, 1 or inf"):
+        engine.moves_prepare(2, [[0, 1]] * E, [0] * E, 0.5)
+    engine.close()

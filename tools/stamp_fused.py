@@ -22,6 +22,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 def main():
     group = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    variant = sys.argv[3] if len(sys.argv) > 3 else "auto"
     build = importlib.import_module("muzero-hypermodel_amd.build")
     out_dir = os.path.join(ROOT, "tools", "_stamps")
     os.makedirs(out_dir, exist_ok=True)
@@ -39,6 +40,11 @@ def main():
     model, _ = cartpole_model_and_weights(models, config, "cuda")
     engine = engine_mod.BatchedMCTS(config, E, group_width=group)
     engine.configure_fused_fc(model)
+    engine.set_fused_options(variant, publish_tree=False)
+    variant = engine.fused_variant()
+    if variant == "narrow":
+        names_narrow = {8: "  descend: fetch child records", 9: "  descend: score (table + division)",
+                        10: "  descend: arg-max + ties", 11: "  descend: publish + loop"}
     lib = native.load()
     lib.mzmcts_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int32]
     obs = torch.from_numpy(np.random.RandomState(0).uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).cuda()
@@ -55,11 +61,16 @@ def main():
     names = ["stage tables+weights", "root inference+expand", "descend", "fc_recurrent", "decode+softmax",
              "write children+hidden", "backup", "publish", "  fc: stage x", "  fc: dynamics L1", "  fc: dynamics L2",
              "  fc: (pre 3)", "  fc: rescale", "  fc: heads L1", "  fc: heads L2", "  fc: (post 3)"]
-    trees_per_wg = 64 // group
+    if variant == "narrow":
+        for k, v in names_narrow.items():
+            names[k] = v
+    trees_per_wg = 16 if variant == "narrow" else 64 // group      # narrow: 4 wavefronts per workgroup at this size
     wgs = (E + trees_per_wg - 1) // trees_per_wg
     total = sum(sums)
-    print(f"group={group} E={E} workgroups={wgs}: mean cycles per workgroup per move, share")
+    print(f"variant={variant} group={group} E={E} workgroups={wgs}: mean cycles per workgroup per move, share")
     for n, v in zip(names, sums):
+        if not v:
+            continue
         per = v / wgs / moves
         print(f"  {n:26s} {per:12.0f} cycles  {100 * v / total:5.1f}%   per-sim {per / config.num_simulations:9.0f}")
     print(f"  total {total / wgs / moves:.0f} cycles per workgroup per move")
