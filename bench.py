@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="envs (trees) per GPU")
-    ap.add_argument("--bcast-every", type=int, default=10, help="weight broadcast period in steps (N>1)")
+    ap.add_argument("--bcast-every", type=int, default=25, help="weight broadcast period in steps (N>1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -62,7 +62,10 @@ def parse_args():
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
     ap.add_argument("--groups", type=int, default=2,
-                    help="fused mode: env groups per GPU searched concurrently on separate HIP streams")
+                    help="fused mode with --moves-per-batch 0: env groups per GPU on separate HIP streams")
+    ap.add_argument("--moves-per-batch", type=int, default=25,
+                    help="fused mode: moves queued back to back per host round trip (mzmcts_moves_*); "
+                         "0 = one host round trip per move, pipelined over --groups env groups")
     return ap.parse_args()
 
 
@@ -107,7 +110,39 @@ def main():
         engine.sample_actions(temperature)
 
     pipe = None
-    if fused and args.groups > 1:
+    batched = fused and args.moves_per_batch > 0
+    if batched:
+        engine.set_fused_options("auto", publish_tree=False)     # MCTS.run's callers consume the root only
+        flat_obs = [o.reshape(E, -1).contiguous() for o in obs_sets]
+
+        def batch_sizes(start, count):
+            i, out = start, []
+            while count > 0:
+                b = min(args.moves_per_batch, count)
+                if world > 1 and args.bcast_every:
+                    b = min(b, args.bcast_every - i % args.bcast_every)
+                out.append((i, b))
+                i += b
+                count -= b
+            return out
+
+        def run_plan(plan, trailing_predraw):
+            """Batches plan[i] = (first step, moves); the first one must already be drawn and uploaded.  The host
+            draws a batch's exploration noise while the previous batch runs and collects actions / visit counts /
+            root values of a batch when it is done; kernels of one batch follow each other without host round
+            trips.  trailing_predraw = (moves) draws one more batch during the last one (left uploaded-ready)."""
+            for n, (i, b) in enumerate(plan):
+                if world > 1 and args.bcast_every and i % args.bcast_every == 0:
+                    actor.refresh_weights(src=0)
+                for k in range(b):
+                    engine.moves_enqueue(flat_obs[(i + k) % len(flat_obs)])
+                nxt = plan[n + 1][1] if n + 1 < len(plan) else trailing_predraw
+                if nxt:
+                    engine.moves_predraw_next(nxt, legal, to_play, temperature, True, num_legal=num_legal)
+                engine.moves_collect()
+                if n + 1 < len(plan):
+                    engine.moves_submit_next()
+    elif fused and args.groups > 1:
         # n env groups on n streams: one group's host work overlaps the other groups' kernels
         n = args.groups
         pipe = engine_mod.PipelinedSearch(config, E, model, actor.flat, groups=n, device=device,
@@ -140,18 +175,37 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
-        one_step(i)
+    if batched:
+        warm, timed = batch_sizes(0, args.warmup), batch_sizes(args.warmup, args.steps)
+        engine.moves_prepare(max(b for _, b in warm + timed), legal, to_play, temperature, True, num_legal=num_legal)
+        engine.moves_collect()                           # (sizes the batch buffers once; nothing was queued)
+        if warm:
+            engine.moves_prepare(warm[0][1], legal, to_play, temperature, True, num_legal=num_legal)
+            run_plan(warm, timed[0][1])                  # steady state: the first timed batch is drawn during warm-up
+    else:
+        for i in range(args.warmup):
+            one_step(i)
     if pipe:
         drain()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
+    if batched:
+        # every timed batch is uploaded, run and collected inside the timed region, and so is one noise draw per
+        # batch (the last batch's draw produces rows nobody runs: it stands in for the first batch's, done above)
+        if warm:
+            engine.moves_submit_next()
+        else:
+            engine.moves_prepare(timed[0][1], legal, to_play, temperature, True, num_legal=num_legal)
+        run_plan(timed, timed[-1][1])
+    else:
+        for i in range(args.steps):
+            one_step(i)
     if pipe:
         drain()                                          # every queued move is finished inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    if batched:
+        engine.moves_discard_next()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -169,7 +223,9 @@ def main():
                    "network": "fullyconnected (reference checkpoint), fp32 inference "
                               + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm"),
                    "mode": args.mode, "lanes_per_tree": engine.group_width(),
-                   "env_groups_per_gpu": args.groups if (fused and args.groups > 1) else 1,
+                   "env_groups_per_gpu": args.groups if (fused and not batched and args.groups > 1) else 1,
+                   "moves_per_host_round_trip": args.moves_per_batch if batched else 1,
+                   "fused_kernel": engine.fused_variant() if fused else None,
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
                    "parallelism": f"actors{world}",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
@@ -219,8 +275,11 @@ def roofline_leg(engine, one_step, steps, device):
                          "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None}
     dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
     d = kernels[dominant]
-    traffic, traffic_source = pmc_traffic(f"mz::{dominant}_kernel", engine.E)
-    roofline = {"bound": "hbm", "kernel": f"mz::{dominant}_kernel", "achieved": d["achieved_GBs"],
+    kernel_name = f"mz::{dominant}_kernel"
+    if dominant == "search_fused_fc" and engine.fused_variant() == "narrow":
+        kernel_name = "mz::search_fused_narrow_kernel"
+    traffic, traffic_source = pmc_traffic(kernel_name, engine.E)
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": d["achieved_GBs"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_kernel_us": d["avg_us"], "mean_select_depth": mean_depth,

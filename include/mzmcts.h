@@ -257,6 +257,10 @@ int32_t mzmcts_fused_variant(mzmcts_engine *engine);
  * path.  Legal action sets are those of a game whose action set does not change between moves (the Dirichlet
  * dimension must be known in advance); temperature must be 0, 1 or +inf per env (+inf: one move per batch).
  *   prepare   blocking host work (noise rows of the whole batch) + asynchronous uploads
+ *   predraw_next / submit_next
+ *             the same in two halves, so that the host draws batch b+1 WHILE batch b runs: predraw_next (any
+ *             time between b's last enqueue and its collect) continues the RNG mirror past b under the same
+ *             assumptions; collect(b) redraws the rows of envs that ended differently; submit_next uploads
  *   enqueue   one search of the prepared batch, asynchronous; observations dev f32[E, obs]
  *   actions   device pointer, i32[E], of move `move`'s sampled actions (valid until the next prepare)
  *   collect   blocking: moves_done i32[E]; per move m < enqueued: actions i32[M,E], visits i32[M,E,A] (root
@@ -265,6 +269,12 @@ int32_t mzmcts_fused_variant(mzmcts_engine *engine);
 int mzmcts_moves_prepare(mzmcts_engine *engine, int32_t n_moves, const int32_t *legal_actions,
                          const int32_t *num_legal, const int32_t *to_play, int32_t add_exploration_noise,
                          const double *temperature, void *stream);
+int mzmcts_moves_predraw_next(mzmcts_engine *engine, int32_t n_moves, const int32_t *legal_actions,
+                              const int32_t *num_legal, const int32_t *to_play, int32_t add_exploration_noise,
+                              const double *temperature);
+int mzmcts_moves_submit_next(mzmcts_engine *engine, void *stream);
+/* Drop a pre-drawn batch that will not be run: the RNG mirror goes back to where the device copy stands. */
+int mzmcts_moves_discard_next(mzmcts_engine *engine);
 int mzmcts_moves_enqueue(mzmcts_engine *engine, const float *observations, void *stream);
 const int32_t *mzmcts_moves_actions(mzmcts_engine *engine, int32_t move);
 int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *actions, int32_t *visits,

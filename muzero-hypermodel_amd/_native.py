@@ -90,6 +90,9 @@ PROTOTYPES = {
     "mzmcts_set_fused_options": (ctypes.c_int, [c_void, ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_fused_variant": (ctypes.c_int32, [c_void]),
     "mzmcts_moves_prepare": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_i32_p, ctypes.c_int32, c_f64_p, c_void]),
+    "mzmcts_moves_predraw_next": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_i32_p, ctypes.c_int32, c_f64_p]),
+    "mzmcts_moves_submit_next": (ctypes.c_int, [c_void, c_void]),
+    "mzmcts_moves_discard_next": (ctypes.c_int, [c_void]),
     "mzmcts_moves_enqueue": (ctypes.c_int, [c_void, c_void, c_void]),
     "mzmcts_moves_actions": (c_void, [c_void, ctypes.c_int32]),
     "mzmcts_moves_collect": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_f64_p, c_f32_p, c_i32_p, c_void]),

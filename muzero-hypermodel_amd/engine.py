@@ -397,9 +397,7 @@ class BatchedMCTS:
         self._check(self._lib.mzmcts_readout_begin(self._h, self._stream()))
 
     # ---- batches of moves without host round trips (include/mzmcts.h: mzmcts_moves_*) -------------------
-    def moves_prepare(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True, num_legal=None):
-        """Draw the exploration noise of the next `n_moves` moves and upload it; the legal action sets must stay
-        the same over the batch, temperature (scalar or [E]) must be 0, 1 or inf."""
+    def _move_inputs(self, legal_actions, to_play, temperature, num_legal):
         if num_legal is not None:
             self._legal[:] = legal_actions
             self._nlegal[:] = num_legal
@@ -413,11 +411,32 @@ class BatchedMCTS:
                 if n:
                     self._legal[e, :n] = legal
         self._to_play[:] = to_play
-        t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+
+    def moves_prepare(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True, num_legal=None):
+        """Draw the exploration noise of the next `n_moves` moves and upload it; the legal action sets must stay
+        the same over the batch, temperature (scalar or [E]) must be 0, 1 or inf."""
+        t = self._move_inputs(legal_actions, to_play, temperature, num_legal)
         self._check(self._lib.mzmcts_moves_prepare(self._h, int(n_moves), self._p_legal, self._p_nlegal, self._p_to_play,
                                                    1 if add_exploration_noise else 0, ptr(t, c_f64_p), self._stream()))
-        self._batch_moves = int(n_moves)
         self._batch_keep = []
+
+    def moves_predraw_next(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True,
+                           num_legal=None):
+        """While a batch is running: draw the following batch's noise (host work overlapped with the GPU)."""
+        t = self._move_inputs(legal_actions, to_play, temperature, num_legal)
+        self._check(self._lib.mzmcts_moves_predraw_next(self._h, int(n_moves), self._p_legal, self._p_nlegal,
+                                                        self._p_to_play, 1 if add_exploration_noise else 0,
+                                                        ptr(t, c_f64_p)))
+
+    def moves_submit_next(self):
+        """After moves_collect: upload the pre-drawn batch; moves_enqueue may follow."""
+        self._check(self._lib.mzmcts_moves_submit_next(self._h, self._stream()))
+        self._batch_keep = []
+
+    def moves_discard_next(self):
+        """Drop a pre-drawn batch that will not be run (the RNG mirror goes back)."""
+        self._check(self._lib.mzmcts_moves_discard_next(self._h))
 
     def moves_enqueue(self, observations):
         """Queue the next search of the prepared batch; `observations`: resident fp32 CUDA tensor [E, obs]."""

@@ -31,14 +31,17 @@ def cartpole_setup(pkg, ties):
     return config, model
 
 
-@pytest.mark.parametrize("group,variant,ties,temps,batch", [
-    (16, "narrow", False, "one", 6),
-    (16, "narrow", True, "one", 4),          # ties at every level: most envs stall after one move per batch
-    (16, "narrow", False, "mixed", 5),       # T = 0 / 1 / inf per env (inf: a single move per batch)
-    (4, "generic", False, "one", 3),
-    (4, "generic", True, "mixed", 3),
+@pytest.mark.parametrize("group,variant,ties,temps,batch,overlap", [
+    (16, "narrow", False, "one", 6, False),
+    (16, "narrow", False, "one", 6, True),     # next batch drawn while the current one runs
+    (16, "narrow", True, "one", 4, False),     # ties at every level: most envs stall after one move per batch
+    (16, "narrow", True, "one", 4, True),
+    (16, "narrow", False, "mixed", 5, False),  # T = 0 / 1 / inf per env (inf: a single move per batch)
+    (16, "narrow", False, "mixed", 5, True),
+    (4, "generic", False, "one", 3, False),
+    (4, "generic", True, "mixed", 3, True),
 ])
-def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, temps, batch):
+def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, temps, batch, overlap):
     config, model = cartpole_setup(pkg, ties)
     E, N = 83, 40 if ties else 24            # N moves per env: > 624 RNG words per env when ties abound
     rs = np.random.RandomState(4)
@@ -52,7 +55,7 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
     ref.configure_fused_fc(model)
     ref.set_fused_options(variant, publish_tree=False)
     want = []
-    for _ in range(N):
+    for _ in range(N + batch + 6):
         st = ref.search_fused(obs, legal, to_play, True)
         actions, _ = ref.sample_actions(T)
         want.append((actions.copy(), st["visits"].copy(), st["root_value_sum"].copy(),
@@ -66,8 +69,17 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
     assert engine.fused_variant() == variant
     rounds = 0
     active = [e for e in range(E) if legal[e]]
+    if overlap:
+        engine.moves_prepare(batch, legal, to_play, T, True)
     while min(len(got[e]) for e in active) < N:
-        out = engine.run_moves([obs] * batch, legal, to_play, T, True)
+        if overlap:
+            for _ in range(batch):
+                engine.moves_enqueue(obs)
+            engine.moves_predraw_next(batch, legal, to_play, T, True)
+            out = engine.moves_collect()
+            engine.moves_submit_next()
+        else:
+            out = engine.run_moves([obs] * batch, legal, to_play, T, True)
         rounds += 1
         assert rounds <= 2 * N + 4
         for e in range(E):
@@ -78,13 +90,28 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
             for m in range(k):
                 got[e].append((out["actions"][m, e], out["visits"][m, e].copy(), out["root_value_sum"][m, e],
                                out["root_predicted"][m, e], out["max_depth"][m, e]))
+    if overlap:
+        engine.moves_collect()             # the batch submitted last: nothing enqueued, every draw is undone
+        # a pre-drawn batch that is dropped must leave the streams where a fresh engine's would be
+        engine.moves_prepare(2, legal, to_play, T, True)
+        engine.moves_enqueue(obs), engine.moves_enqueue(obs)
+        engine.moves_predraw_next(batch, legal, to_play, T, True)
+        a = engine.moves_collect()
+        engine.moves_discard_next()
+        b = engine.run_moves([obs] * 2, legal, to_play, T, True)
+        for e in active:
+            seq = [(a, m) for m in range(a["moves_done"][e])] + [(b, m) for m in range(b["moves_done"][e])]
+            for i, (o, m) in enumerate(seq):
+                n = len(got[e])
+                got[e].append((o["actions"][m, e], o["visits"][m, e].copy(), o["root_value_sum"][m, e],
+                               o["root_predicted"][m, e], o["max_depth"][m, e]))
     engine.close()
     if ties:
         assert rounds >= N // 2             # the tie-breaking searches really did stall the batches
     else:
         assert rounds <= (N // batch + 3) * (batch if temps == "mixed" else 1)
     for e in active:
-        for i in range(N):
+        for i in range(min(len(got[e]), len(want))):
             a, v, rv, pred, depth = got[e][i]
             wa, wv, wrv, wpred, wdepth = want[i]
             assert a == wa[e] and np.array_equal(v, wv[e]), (e, i)
