@@ -42,7 +42,7 @@ int mzenv_shape(const mzenv *env, int32_t *num_actions, int32_t *num_players, in
 /* Game.reset() for every env whose mask byte is non-zero (mask dev u8[E], NULL = all envs). */
 int mzenv_reset(mzenv *env, const uint8_t *mask, void *stream);
 
-/* Game.step(action) for every env (envs with action < 0 are left untouched):
+/* Game.step(action) for every env (envs with action < 0 are left untouched; their reward and done read 0):
  *   actions dev i32[E];  reward_out dev f32[E];  done_out dev u8[E] */
 int mzenv_step(mzenv *env, const int32_t *actions, float *reward_out, uint8_t *done_out, void *stream);
 

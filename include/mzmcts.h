@@ -251,11 +251,12 @@ int32_t mzmcts_fused_variant(mzmcts_engine *engine);
  *
  * The pre-drawn noise assumes what the reference's RNG order implies for the common case -- search m spends
  * one word on UCB tie-breaks (the first simulation's, when every root child still scores 0; tie-break words
- * come ahead of the next Dirichlet draw in the stream) and select_action consumes 0 (T = 0) or 2 (T = 1) words.  Where that fails the env simply is not searched from the next move on (moves_done[e] <
+ * come ahead of the next Dirichlet draw in the stream) and select_action consumes 0 (T = 0) or 2 (T = 1/k) words.  Where that fails the env simply is not searched from the next move on (moves_done[e] <
  * n_moves, its actions read -1: mzenv_step leaves such an env untouched) and the stream mirror is put back;
  * the caller plays the missing moves in the next batch.  Played moves are bit-identical to the one-at-a-time
  * path.  Legal action sets are those of a game whose action set does not change between moves (the Dirichlet
- * dimension must be known in advance); temperature must be 0, 1 or +inf per env (+inf: one move per batch).
+ * dimension must be known in advance); temperature per env must be 0, +inf (one move per batch) or 1/k with
+ * k = 1..4, the values for which visit_count ** (1 / T) is exact integer arithmetic.
  *   prepare   blocking host work (noise rows of the whole batch) + asynchronous uploads
  *   predraw_next / submit_next
  *             the same in two halves, so that the host draws batch b+1 WHILE batch b runs: predraw_next (any

@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams p, const int32_
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.E) return;
     const int a = actions[e];
-    if (a < 0) return;
+    if (a < 0) {  // env left alone this move (e.g. its search was not run): nothing happened
+        reward_out[e] = 0.f;
+        done_out[e] = 0;
+        return;
+    }
     float reward = 0.f;
     bool done = false;
     if (p.game == 0) {

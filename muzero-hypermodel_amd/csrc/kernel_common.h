@@ -94,9 +94,18 @@ __device__ __forceinline__ bool move_stalled(const TreeParams& p, const MoveCtl&
     return stalled;
 }
 
+// Temperatures whose visit_count ** (1 / T) is exact integer arithmetic everywhere: 1 / T an integer k in 1..4
+// (the reference's schedules use 1, 0.5, 0.25: cartpole.py:118-128).  Returns k, or 0.
+__host__ __device__ inline int exact_inverse_temperature(double temperature) {
+    const double inv = 1.0 / temperature;
+    const int k = static_cast<int>(inv);
+    return (inv == static_cast<double>(k) && k >= 1 && k <= 4) ? k : 0;
+}
+
 // SelfPlay.select_action (self_play.py:223-246) on the device copy of the stream, for the temperatures
-// whose arithmetic is exact everywhere: 0 (arg-max), 1 (visits ** 1.0 == visits; normalise, cumulative
-// sum, one legacy double, right-bisect -- RandomState.choice(p=...)) and inf (choice without p).
+// whose arithmetic is exact everywhere: 0 (arg-max), +inf (choice without p) and 1/k (visits ** k by
+// multiplication -- libm's pow returns the same exactly representable integers --, normalise, cumulative
+// sum, one legacy double, right-bisect: RandomState.choice(p=...)).
 // Returns the chosen child slot, or -2 for a temperature the host must handle (pow()).
 template <typename VisitOf>
 __device__ __forceinline__ int device_select_action(VisitOf visit_of, int n, double temperature, uint32_t* key,
@@ -113,11 +122,18 @@ __device__ __forceinline__ int device_select_action(VisitOf visit_of, int n, dou
         return best;
     }
     if (isinf(temperature)) return static_cast<int>(mt_below(key, pos, static_cast<uint32_t>(n), words));
-    if (temperature != 1.0) return -2;
+    const int k = exact_inverse_temperature(temperature);
+    if (k == 0) return -2;
+    auto weight = [&](int i) {
+        const double v = static_cast<double>(visit_of(i));
+        double w = v;
+        for (int r = 1; r < k; ++r) w = w * v;
+        return w;
+    };
     double total = 0.0;
-    for (int i = 0; i < n; ++i) total = total + static_cast<double>(visit_of(i));
+    for (int i = 0; i < n; ++i) total = total + weight(i);
     double total_p = 0.0;
-    for (int i = 0; i < n; ++i) total_p += static_cast<double>(visit_of(i)) / total;
+    for (int i = 0; i < n; ++i) total_p += weight(i) / total;
     const int32_t a = static_cast<int32_t>(mt_next(key, pos) >> 5);
     const int32_t b = static_cast<int32_t>(mt_next(key, pos) >> 6);
     *words += 2u;
@@ -125,7 +141,7 @@ __device__ __forceinline__ int device_select_action(VisitOf visit_of, int n, dou
     double run = 0.0;
     int idx = 0;
     for (; idx < n; ++idx) {
-        run += static_cast<double>(visit_of(idx)) / total;
+        run += weight(idx) / total;
         if (!(run / total_p <= u)) break;
     }
     return idx;

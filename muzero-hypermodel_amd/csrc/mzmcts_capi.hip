@@ -1284,15 +1284,15 @@ static int check_move_inputs(mzmcts_engine* eng, int32_t n_moves, const int32_t*
                 return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
         }
         const double t = temperature[e];
-        if (!(t == 0.0 || t == 1.0 || std::isinf(t)))
-            return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": the device samples actions at temperature 0, 1 or inf "
-                                                                    "only (visit_count ** (1 / T) needs the host's pow)");
+        if (!(t == 0.0 || std::isinf(t) || (mz::exact_inverse_temperature(t) && std::pow(eng->p.S, 1.0 / t) < 9.0e15)))
+            return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": the device samples actions at temperature 0, inf or 1/k, "
+                                                                    "k = 1..4, only (visit_count ** (1 / T) needs the host's pow)");
     }
     return 0;
 }
 
 // words select_action consumes on the device; +inf draws a bounded integer by rejection: unknown in advance
-static int assumed_sample_words(double t) { return (t == 0.0) ? 0 : (t == 1.0 ? 2 : -1); }
+static int assumed_sample_words(double t) { return (t == 0.0) ? 0 : (std::isinf(t) ? -1 : 2); }
 // The first simulation always ties: the root has no visits yet, so every child scores 0 (sqrt(0) in ucb_score,
 // self_play.py:385-390) and select_child draws numpy.random.choice over all n of them -- one masked 32-bit word
 // when n is a power of two, a rejection loop otherwise (one word is the likeliest outcome and the one assumed).

@@ -34,6 +34,8 @@ class DeviceEnvs:
         shape = (ctypes.c_int32 * 3)()
         self._lib.mzenv_shape(self._h, ctypes.byref(a), ctypes.byref(p), shape)
         self.A, self.players, self.observation_shape = a.value, p.value, tuple(shape)
+        self.constant_legal_actions = game == "cartpole"     # every action legal in every state
+        self.max_episode_steps = {"cartpole": 500, "tictactoe": 9, "connect4": 42}[game]
         with torch.cuda.device(self.device):
             self.obs = torch.zeros((self.E, *self.observation_shape), dtype=torch.float32, device=self.device)
             self.legal = torch.zeros((self.E, self.A), dtype=torch.int32, device=self.device)
@@ -67,19 +69,26 @@ class DeviceEnvs:
         self._keep = mask
         self._check(self._lib.mzenv_reset(self._h, None if mask is None else mask.data_ptr(), self._stream()))
 
-    def step(self, actions):
+    def step(self, actions, reward=None, done=None):
         """Game.step per env; `actions`: int array / tensor [E] (negative = leave that env alone).
-        Returns (reward, done) device tensors (valid until the next step)."""
-        if torch.is_tensor(actions):
-            self._actions.copy_(actions.to(torch.int32), non_blocking=True)
+        Returns (reward, done) device tensors: the caller's `reward` (f32 [E]) / `done` (u8 [E]) when given,
+        otherwise this object's own buffers (valid until the next step)."""
+        if torch.is_tensor(actions) and actions.is_cuda and actions.dtype == torch.int32 and actions.is_contiguous():
+            src = actions                                    # e.g. the search's own action buffer: no copy
+        elif torch.is_tensor(actions):
+            src = self._actions.copy_(actions.to(torch.int32), non_blocking=True)
         else:
-            self._actions.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32)), non_blocking=True)
-        self._check(self._lib.mzenv_step(self._h, self._actions.data_ptr(), self.reward.data_ptr(),
-                                         self.done.data_ptr(), self._stream()))
-        return self.reward, self.done
+            src = self._actions.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.int32)), non_blocking=True)
+        reward = self.reward if reward is None else reward
+        done = self.done if done is None else done
+        self._keep_step = (src, reward, done)
+        self._check(self._lib.mzenv_step(self._h, src.data_ptr(), reward.data_ptr(), done.data_ptr(), self._stream()))
+        return reward, done
 
-    def observe(self):
-        """(observations [E,C,H,W] f32, legal [E,A] i32, num_legal [E] i32, to_play [E] i32) device tensors."""
-        self._check(self._lib.mzenv_observe(self._h, self.obs.data_ptr(), self.legal.data_ptr(),
+    def observe(self, obs=None):
+        """(observations [E,C,H,W] f32, legal [E,A] i32, num_legal [E] i32, to_play [E] i32) device tensors;
+        the observations go to the caller's `obs` buffer when given."""
+        obs = self.obs if obs is None else obs
+        self._check(self._lib.mzenv_observe(self._h, obs.data_ptr(), self.legal.data_ptr(),
                                             self.num_legal.data_ptr(), self.to_play.data_ptr(), self._stream()))
-        return self.obs, self.legal, self.num_legal, self.to_play
+        return obs, self.legal, self.num_legal, self.to_play

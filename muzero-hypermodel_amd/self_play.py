@@ -607,7 +607,9 @@ class DeviceSelfPlay:
 
     def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
         """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
-        cfg, cur, rows = self.config, self._cur, self._rows
+        self._drop_batch()
+        self.flush(on_game, on_games)
+        cur = self._cur
         self.engine.search(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True, num_legal=cur["num_legal"])
         if temperature_threshold:
             # play_game: temperature only while len(action_history) < threshold (self_play.py:163-170)
@@ -617,19 +619,33 @@ class DeviceSelfPlay:
         actions, _ = self.engine.sample_actions(numpy.ascontiguousarray(temps, dtype=numpy.float64))
         child_visits, root_values = self.engine.search_statistics()
         reward, done = self.envs.step(actions)
-        nxt = self._observe_host()
+        after = self._observe_host()
         reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
-        at = self._len
-        self._cv[rows, at] = child_visits
-        self._rv[rows, at] = root_values
-        self._act[rows, at + 1] = actions
-        self._rew[rows, at + 1] = reward
-        self._obs[rows, at + 1] = nxt["obs"]
-        self._tp[rows, at + 1] = nxt["to_play"]
-        self._len = at + 1
-        over = done | (self._len + 1 > cfg.max_moves)      # len(action_history) > max_moves ends the game
+        over = done | (self._len + 2 > self.config.max_moves)   # len(action_history) > max_moves ends the game
+        nxt = after
         if over.any():
-            idx = numpy.flatnonzero(over)
+            self.envs.reset(torch.from_numpy(over.astype(numpy.uint8)).to(self.device))
+            nxt = self._observe_host()
+        self._file_move(numpy.ones(self.E, dtype=bool), actions, child_visits, root_values, reward, over,
+                        after["obs"], after["to_play"], nxt["obs"], nxt["to_play"], on_game, on_games)
+        self._cur = nxt
+        self.moves_played += self.E
+
+    def _file_move(self, played, actions, child_visits, root_values, reward, over, obs_after, to_play_after,
+                   obs_next, to_play_next, on_game, on_games):
+        """File one move of the envs in `played` into their history rows; hand finished games (`over`) out
+        and start their next game from obs_next (the reset observation)."""
+        rows = numpy.flatnonzero(played)
+        at = self._len[rows]
+        self._cv[rows, at] = child_visits[rows]
+        self._rv[rows, at] = root_values[rows]
+        self._act[rows, at + 1] = actions[rows]
+        self._rew[rows, at + 1] = reward[rows]
+        self._obs[rows, at + 1] = obs_after[rows]
+        self._tp[rows, at + 1] = to_play_after[rows]
+        self._len[rows] = at + 1
+        idx = numpy.flatnonzero(over & played)
+        if len(idx):
             n = self._len[idx]
             L = int(n.max())
             batch = PackedGames(env_index=idx, length=n, observations=self._obs[idx, : L + 1],
@@ -641,16 +657,78 @@ class DeviceSelfPlay:
             if on_game is not None:
                 for i, e in enumerate(idx):
                     on_game(int(e), batch.history(i))
-            self.envs.reset(torch.from_numpy(over.astype(numpy.uint8)).to(self.device))
-            fresh = self._observe_host()
-            for key in ("obs", "legal", "num_legal", "to_play"):
-                nxt[key][idx] = fresh[key][idx]
-            nxt["obs_dev"] = fresh["obs_dev"]
             self._len[idx] = 0
-            self._obs[idx, 0] = fresh["obs"][idx]
-            self._tp[idx, 0] = fresh["to_play"][idx]
-        self._cur = nxt
-        self.moves_played += self.E
+            self._obs[idx, 0] = obs_next[idx]
+            self._tp[idx, 0] = to_play_next[idx]
+
+    # ---- whole batches of moves on the device (engine.moves_*, include/mzmcts.h) ---------------------------
+    def play_moves(self, n_moves, temperature, on_game=None, on_games=None):
+        """`n_moves` moves of every env with no host round trip in between: search (which samples the action),
+        env step, terminal observation, reset of finished envs, next observation -- all queued on one stream;
+        the exploration noise of the whole batch is drawn up front (and the next batch's while this one runs).
+        Needs a game whose legal action set never changes (CartPole) and a fully-connected network.
+        An env may come back with fewer than n_moves moves played (it plays the rest next time)."""
+        E, eng, envs, cfg = self.E, self.engine, self.envs, self.config
+        if not getattr(envs, "constant_legal_actions", False):
+            raise NotImplementedError("play_moves needs a game whose legal action set never changes")
+        if cfg.max_moves < envs.max_episode_steps:
+            raise NotImplementedError("play_moves ends games where the environment does; max_moves is shorter")
+        cur = self._cur
+        params = (int(n_moves), float(temperature))
+        if getattr(self, "_batch_ready", None) != params:
+            self._drop_batch()
+            eng.moves_prepare(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
+        ring = self._move_ring(n_moves)
+        obs_in = cur["obs_dev"]
+        for m in range(n_moves):
+            eng.moves_enqueue(obs_in.reshape(E, -1))
+            envs.step(eng.moves_actions(m), ring["reward"][m], ring["done"][m])
+            envs.observe(ring["obs_after"][m])               # terminal observations included
+            envs.reset(ring["done"][m])
+            obs_in = envs.observe(ring["obs_next"][m])[0]    # reset observations where a game ended
+        self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
+        eng.moves_predraw_next(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
+        out = eng.moves_collect()
+        host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
+        eng.moves_submit_next()
+        self._batch_ready = params
+        self._unfiled = (out, host, cur["legal"], cur["to_play"], n_moves)
+        self._cur = dict(cur, obs_dev=obs_in, obs=host["obs_next"][n_moves - 1])
+        self.moves_played += int(out["moves_done"].sum())
+        return out["moves_done"]
+
+    def flush(self, on_game=None, on_games=None):
+        """File the moves of the last play_moves batch into the histories (play_moves does this for the
+        batch before while the GPU runs the current one; call it once at the end)."""
+        if getattr(self, "_unfiled", None) is None:
+            return
+        out, host, legal, to_play, n_moves = self._unfiled
+        self._unfiled = None
+        S = float(self.config.num_simulations)
+        done = host["done"].astype(bool)
+        for m in range(n_moves):
+            child_visits = numpy.zeros((self.E, self.envs.A))
+            numpy.put_along_axis(child_visits, legal.astype(numpy.int64), out["visits"][m] / S, axis=1)
+            self._file_move(out["moves_done"] > m, out["actions"][m], child_visits, out["root_value_sum"][m] / S,
+                            host["reward"][m], done[m], host["obs_after"][m], to_play, host["obs_next"][m], to_play,
+                            on_game, on_games)
+
+    def _drop_batch(self):
+        """Forget the batch that was drawn and uploaded ahead (its noise goes back into the RNG streams)."""
+        if getattr(self, "_batch_ready", None):
+            self.engine.moves_collect()
+            self._batch_ready = None
+
+    def _move_ring(self, n_moves):
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring["reward"].shape[0] < n_moves:
+            shape, dev = self.envs.observation_shape, self.device
+            ring = dict(reward=torch.zeros((n_moves, self.E), dtype=torch.float32, device=dev),
+                        done=torch.zeros((n_moves, self.E), dtype=torch.uint8, device=dev),
+                        obs_after=torch.zeros((n_moves, self.E) + shape, dtype=torch.float32, device=dev),
+                        obs_next=torch.zeros((n_moves, self.E) + shape, dtype=torch.float32, device=dev))
+            self._ring = ring
+        return ring
 
     def close(self):
         self.envs.close()

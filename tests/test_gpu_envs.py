@@ -104,3 +104,43 @@ def test_device_self_play_cartpole_fused(dev, pkg):
         n = len(gh.action_history)
         assert 2 <= n <= config.max_moves + 1 and len(gh.child_visits) == n - 1 == len(gh.root_values)
         assert all(abs(sum(cv) - 1.0) < 1e-12 for cv in gh.child_visits)
+
+
+def test_device_self_play_in_move_batches_equals_move_by_move(dev, pkg):
+    """play_moves (searches, env steps, resets queued back to back, noise drawn ahead) plays the same games
+    as step() (one host round trip per move)."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("cartpole").MuZeroConfig()
+    torch.manual_seed(0)       # random weights: a poor player, games end within a couple of dozen moves
+    weights = models_mod.MuZeroNetwork(config).get_weights()
+    E, total = 96, 120
+    finished = {}
+    for kind in ("step", "batch"):
+        games_done = {}
+        actor = sp.DeviceSelfPlay({"weights": weights}, "cartpole", config, 0, E)
+
+        def on_games(batch):
+            for i, e in enumerate(batch.env_index):
+                games_done.setdefault(int(e), []).append(batch.history(i))
+        if kind == "step":
+            for _ in range(total):
+                actor.step(1.0, None, on_games=on_games)
+        else:
+            played = np.zeros(E, np.int64)
+            while played.min() < total:
+                played += actor.play_moves(8, 1.0, on_games=on_games)
+            actor.step(1.0, None, on_games=on_games)        # mixing the two drops the batch drawn ahead
+            actor.flush(on_games=on_games)
+        actor.close()
+        finished[kind] = games_done
+    compared = 0
+    for e in range(E):
+        a, b = finished["step"].get(e, []), finished["batch"].get(e, [])
+        for ga, gb in zip(a, b):
+            assert ga.action_history == gb.action_history and ga.reward_history == gb.reward_history, e
+            assert np.array_equal(np.array(ga.child_visits), np.array(gb.child_visits))
+            assert ga.root_values == gb.root_values
+            assert all(np.array_equal(x, y) for x, y in zip(ga.observation_history, gb.observation_history))
+            compared += 1
+    assert compared >= E // 2

@@ -36,7 +36,7 @@ def cartpole_setup(pkg, ties):
     (16, "narrow", False, "one", 6, True),     # next batch drawn while the current one runs
     (16, "narrow", True, "one", 4, False),     # ties at every level: most envs stall after one move per batch
     (16, "narrow", True, "one", 4, True),
-    (16, "narrow", False, "mixed", 5, False),  # T = 0 / 1 / inf per env (inf: a single move per batch)
+    (16, "narrow", False, "mixed", 5, False),  # T = 0 / 1 / inf / 0.5 / 0.25 per env (inf: a single move per batch)
     (16, "narrow", False, "mixed", 5, True),
     (4, "generic", False, "one", 3, False),
     (4, "generic", True, "mixed", 3, True),
@@ -48,7 +48,7 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
     obs = torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()   # same observation every move
     legal = [[0, 1] if e % 11 else [] for e in range(E)]                                # a few inactive envs
     to_play = [0] * E
-    T = np.ones(E) if temps == "one" else np.array([[0.0, 1.0, np.inf, 1.0][e % 4] for e in range(E)])
+    T = np.ones(E) if temps == "one" else np.array([[0.0, 1.0, np.inf, 0.5, 0.25][e % 5] for e in range(E)])
     seeds = [1000 + e for e in range(E)]
 
     ref = eng.BatchedMCTS(config, E, seeds=seeds, group_width=group)
@@ -134,6 +134,6 @@ def test_move_batch_actions_are_on_the_device(eng, pkg):
         assert np.array_equal(on_device[m].cpu().numpy(), out["actions"][m])
     with pytest.raises(RuntimeError):
         engine.moves_collect()
-    with pytest.raises(RuntimeError, match="temperature 0, 1 or inf"):
-        engine.moves_prepare(2, [[0, 1]] * E, [0] * E, 0.5)
+    with pytest.raises(RuntimeError, match="temperature 0, inf or 1/k"):
+        engine.moves_prepare(2, [[0, 1]] * E, [0] * E, 0.3)
     engine.close()

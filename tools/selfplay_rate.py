@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--moves", type=int, default=60)
     ap.add_argument("--kinds", default="host,device")
+    ap.add_argument("--batch", type=int, default=20, help="moves per host round trip of the device-batch actor")
     args = ap.parse_args()
     mod = importlib.import_module(f"muzero-hypermodel_amd.games.{args.game}")
     config = mod.MuZeroConfig()
@@ -34,6 +35,8 @@ def main():
             actor = sp.BatchedSelfPlay({"weights": weights}, mod.Game, config, 0, args.envs)
         else:
             actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs)
+            if kind == "device-batch":
+                actor.engine.set_fused_options("auto", publish_tree=False)
         done = [0]
 
         def on_game(e, gh):
@@ -43,18 +46,31 @@ def main():
             done[0] += len(batch)
 
         cb = dict(on_game=on_game) if kind in ("host", "device-lists") else dict(on_games=on_games)
-        for _ in range(5):
-            actor.step(1.0, None, **cb)
-        torch.cuda.synchronize()
-        done[0] = 0
-        t0 = time.perf_counter()
-        for _ in range(args.moves):
-            actor.step(1.0, None, **cb)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        moves = args.moves * args.envs
+        if kind == "device-batch":
+            # searches, env steps and resets queued back to back, `--batch` moves per host round trip
+            actor.play_moves(args.batch, 1.0, **cb)
+            torch.cuda.synchronize()
+            done[0] = 0
+            t0 = time.perf_counter()
+            moves = 0
+            for _ in range(max(1, args.moves // args.batch)):
+                moves += int(actor.play_moves(args.batch, 1.0, **cb).sum())
+            actor.flush(**cb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        else:
+            for _ in range(5):
+                actor.step(1.0, None, **cb)
+            torch.cuda.synchronize()
+            done[0] = 0
+            t0 = time.perf_counter()
+            for _ in range(args.moves):
+                actor.step(1.0, None, **cb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            moves = args.moves * args.envs
         print(json.dumps({"actor": kind, "game": args.game, "envs": args.envs, "moves_per_s": moves / dt,
-                          "simulations_per_s": moves * config.num_simulations / dt, "ms_per_move_step": 1e3 * dt / args.moves,
+                          "simulations_per_s": moves * config.num_simulations / dt, "ms_per_move_step": 1e3 * dt * args.envs / moves,
                           "games_finished": done[0]}), flush=True)
         actor.close()
 
