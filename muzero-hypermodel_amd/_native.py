@@ -100,6 +100,14 @@ PROTOTYPES = {
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
     # include/mzenv.h
+    "mzreplay_create": (ctypes.c_int, [c_void, ctypes.POINTER(c_void)]),
+    "mzreplay_destroy": (None, [c_void]),
+    "mzreplay_last_error": (ctypes.c_char_p, [c_void]),
+    "mzreplay_add_games": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_f32_p, c_i32_p, c_f64_p, c_i32_p,
+                                          c_f64_p, c_f64_p, c_f32_p, c_f32_p, c_void]),
+    "mzreplay_make_batch": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_i32_p, c_void, c_void, c_void,
+                                           c_void, c_void, c_void, c_void]),
+    "mzreplay_device_bytes": (ctypes.c_int64, [c_void]),
     "mzenv_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u32_p, ctypes.POINTER(c_void)]),
     "mzenv_destroy": (None, [c_void]),
     "mzenv_last_error": (ctypes.c_char_p, [c_void]),

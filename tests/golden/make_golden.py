@@ -600,6 +600,88 @@ def g11_envs(ctx):
         save(f"g11_{name}_env", **{k: numpy.array(v) for k, v in rows.items()})
 
 
+def _synthetic_history(self_play, rs, config, length):
+    """A GameHistory with the field types play_game leaves behind (self_play.py:116-121, 176-182, 497-512):
+    numpy observations, int actions, float rewards, int to_play, child_visits = lists of floats, float root values."""
+    A, P = len(config.action_space), len(config.players)
+    gh = self_play.GameHistory()
+    to_play = int(rs.randint(0, P))
+    gh.action_history.append(0)
+    gh.observation_history.append(rs.standard_normal(config.observation_shape).astype("float32"))
+    gh.reward_history.append(0)
+    gh.to_play_history.append(to_play)
+    for _ in range(length):
+        visits = rs.multinomial(config.num_simulations, rs.dirichlet([0.6] * A))
+        gh.child_visits.append([int(v) / config.num_simulations for v in visits])
+        gh.root_values.append(float(rs.standard_normal() * 3))
+        gh.action_history.append(int(rs.randint(0, A)))
+        gh.observation_history.append(rs.standard_normal(config.observation_shape).astype("float32"))
+        gh.reward_history.append(float(numpy.float32(rs.standard_normal())) if P == 1 else float(rs.randint(0, 2)))
+        to_play = (to_play + 1) % P
+        gh.to_play_history.append(to_play)
+    return gh
+
+
+def g12_replay_targets(ctx):
+    """ReplayBuffer.save_game (initial priorities), get_batch / make_target / compute_target_value and the
+    observation stacking (replay_buffer.py:33-65, 67-133, 222-295) on synthetic game histories."""
+    import copy
+    import replay_buffer
+    self_play, cfgs = ctx["self_play"], ctx["configs"]
+    for name, tweak in (("cartpole", {}), ("tictactoe", {}), ("tictactoe_stacked", {"stacked_observations": 2}),
+                        ("cartpole_uniform", {"PER": False})):
+        config = copy.deepcopy(cfgs[name.split("_")[0]])
+        for k, v in tweak.items():
+            setattr(config, k, v)
+        config.batch_size = 48
+        rs = numpy.random.RandomState(77)
+        lengths = [int(v) for v in rs.randint(1, 70 if len(config.players) == 1 else 10, 24)]
+        games = [_synthetic_history(self_play, rs, config, n) for n in lengths]
+        rb = replay_buffer.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+        for gh in games:
+            rb.save_game(gh)
+        index_batch, (obs_b, act_b, val_b, rew_b, pol_b, w_b, gs_b) = rb.get_batch()
+        L = max(lengths)
+        A = len(config.action_space)
+        G = len(games)
+        out = dict(config_scalars(config))
+        out.update(td_steps=config.td_steps, num_unroll_steps=config.num_unroll_steps, PER=int(config.PER),
+                   PER_alpha=config.PER_alpha, stacked_observations=config.stacked_observations,
+                   observation_shape=numpy.array(config.observation_shape), batch_size=config.batch_size,
+                   seed=config.seed, lengths=numpy.array(lengths, dtype="int32"))
+        obs = numpy.zeros((G, L + 1) + tuple(config.observation_shape), dtype="float32")
+        act = numpy.zeros((G, L + 1), dtype="int32")
+        rew = numpy.zeros((G, L + 1), dtype="float64")
+        tp = numpy.zeros((G, L + 1), dtype="int32")
+        cv = numpy.zeros((G, L, A), dtype="float64")
+        rv = numpy.zeros((G, L), dtype="float64")
+        pri = numpy.zeros((G, L), dtype="float32")
+        game_pri = numpy.zeros(G, dtype="float32")
+        for g, gh in enumerate(games):
+            n = lengths[g]
+            obs[g, : n + 1] = numpy.array(gh.observation_history)
+            act[g, : n + 1] = gh.action_history
+            rew[g, : n + 1] = gh.reward_history
+            tp[g, : n + 1] = gh.to_play_history
+            cv[g, :n] = gh.child_visits
+            rv[g, :n] = gh.root_values
+            if config.PER:
+                pri[g, :n] = gh.priorities
+                game_pri[g] = gh.game_priority
+        out.update(observations=obs, actions=act, rewards=rew, to_play=tp, child_visits=cv, root_values=rv,
+                   priorities=pri, game_priority=game_pri,
+                   index_batch=numpy.array(index_batch, dtype="int64"),
+                   observation_batch=numpy.array(obs_b, dtype="float32"),
+                   action_batch=numpy.array(act_b, dtype="int64"),
+                   value_batch=numpy.array(val_b, dtype="float64"),
+                   reward_batch=numpy.array(rew_b, dtype="float64"),
+                   policy_batch=numpy.array(pol_b, dtype="float64"),
+                   gradient_scale_batch=numpy.array(gs_b, dtype="float64"))
+        if config.PER:
+            out["weight_batch"] = numpy.array(w_b, dtype="float32")
+        save(f"g12_replay_{name}", **out)
+
+
 def make_configs():
     import games.tictactoe as ttt
     import games.connect4 as c4
@@ -620,7 +702,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets]
 
 
 def main():

@@ -1,0 +1,114 @@
+"""Device replay store (include/mzreplay.h) against the reference's ReplayBuffer (fixtures G12)
+and the oracle restatement: priorities to float32 rounding, sampled indices / values / rewards / policies /
+actions / gradient scales / stacked observations / importance weights bit for bit."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from parity_helpers import load_golden
+from test_oracle_replay import NAMES, cfg_of, games_of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def config_of(fx, name):
+    mod = importlib.import_module(f"muzero-hypermodel_amd.games.{name.split('_')[0]}")
+    config = mod.MuZeroConfig()
+    config.batch_size = int(fx["batch_size"])
+    config.stacked_observations = int(fx["stacked_observations"])
+    config.PER = bool(fx["PER"])
+    assert config.td_steps == int(fx["td_steps"]) and config.num_unroll_steps == int(fx["num_unroll_steps"])
+    assert config.seed == int(fx["seed"]) and float(config.discount) == float(fx["cfg_discount"])
+    return config
+
+
+def history_of(sp, fx, g):
+    n = int(fx["lengths"][g])
+    gh = sp.GameHistory()
+    gh.observation_history = [o for o in fx["observations"][g, : n + 1]]
+    gh.action_history = [int(a) for a in fx["actions"][g, : n + 1]]
+    gh.reward_history = [float(r) for r in fx["rewards"][g, : n + 1]]
+    gh.to_play_history = [int(t) for t in fx["to_play"][g, : n + 1]]
+    gh.child_visits = [[float(v) for v in row] for row in fx["child_visits"][g, :n]]
+    gh.root_values = [float(v) for v in fx["root_values"][g, :n]]
+    return gh
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("packed", [False, True])
+def test_replay_store_matches_reference(pkg, name, packed):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    rb_mod = importlib.import_module("muzero-hypermodel_amd.replay_buffer")
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    fx = load_golden(f"g12_replay_{name}")
+    config = config_of(fx, name)
+    G = len(fx["lengths"])
+    rb = rb_mod.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    if packed:
+        L = fx["actions"].shape[1] - 1
+        batch = sp.PackedGames(env_index=np.arange(G), length=fx["lengths"], observations=fx["observations"],
+                               actions=fx["actions"], rewards=fx["rewards"], to_play=fx["to_play"],
+                               child_visits=fx["child_visits"], root_values=fx["root_values"])
+        assert L <= config.max_moves
+        rb.save_games(batch)
+    else:
+        for g in range(G):
+            rb.save_game(history_of(sp, fx, g))
+    assert rb.num_played_games == G and rb.total_samples == int(fx["lengths"].sum())
+    if config.PER:
+        for g in range(G):
+            n = int(fx["lengths"][g])
+            want = fx["priorities"][g, :n]
+            got = rb.buffer[g]["priorities"]
+            # |root - target| ** alpha goes through the device's pow(): equal up to one float32 rounding step
+            np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+            assert abs(rb.buffer[g]["game_priority"] - fx["game_priority"][g]) <= 2e-7 * fx["game_priority"][g]
+            # sample with the reference's priorities, so that the draws below can be compared one for one
+            rb.buffer[g]["priorities"] = want.copy()
+            rb.buffer[g]["game_priority"] = fx["game_priority"][g]
+    index_batch, (obs, act, val, rew, pol, weight, scale) = rb.get_batch()
+    assert np.array_equal(np.array(index_batch), fx["index_batch"])
+    assert np.array_equal(act.cpu().numpy(), fx["action_batch"])
+    assert np.array_equal(val.cpu().numpy(), fx["value_batch"])            # fp64, the reference's summation order
+    assert np.array_equal(rew.cpu().numpy(), fx["reward_batch"])
+    assert np.array_equal(pol.cpu().numpy(), fx["policy_batch"])
+    assert np.array_equal(scale.cpu().numpy(), fx["gradient_scale_batch"])
+    assert np.array_equal(obs.cpu().numpy(), fx["observation_batch"])
+    if config.PER:
+        assert np.array_equal(weight, fx["weight_batch"])
+    rb.close()
+
+
+def test_replay_store_ring_and_priority_updates(pkg):
+    rb_mod = importlib.import_module("muzero-hypermodel_amd.replay_buffer")
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    ro = importlib.import_module("replay_oracle")
+    fx = load_golden("g12_replay_cartpole")
+    config = config_of(fx, "cartpole")
+    config.replay_buffer_size = 10                      # smaller than the 24 games: the oldest are dropped
+    rb = rb_mod.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    for g in range(len(fx["lengths"])):
+        rb.save_game(history_of(sp, fx, g))
+    assert sorted(rb.buffer) == list(range(14, 24)) and rb.total_samples == int(fx["lengths"][14:].sum())
+    games, cfg = games_of(fx, ro), cfg_of(fx)
+    index_batch, (obs, act, val, rew, pol, weight, scale) = rb.get_batch()
+    val = val.cpu().numpy()
+    for b, (gid, pos) in enumerate(index_batch):
+        assert 14 <= gid < 24
+        for u in range(config.num_unroll_steps + 1):
+            if pos + u < fx["lengths"][gid]:
+                assert val[b, u] == ro.compute_target_value(games[gid], pos + u, cfg["td_steps"], cfg["discount"])
+    # update_priorities (replay_buffer.py:197-220)
+    gid, pos = index_batch[0]
+    new = np.full((1, config.num_unroll_steps + 1), 7.5, dtype=np.float32)
+    rb.update_priorities(new, [(gid, pos)])
+    n = rb.buffer[gid]["length"]
+    assert (rb.buffer[gid]["priorities"][pos: min(n, pos + 11)] == 7.5).all() and rb.buffer[gid]["game_priority"] == 7.5
+    rb.close()
