@@ -298,6 +298,11 @@ uint32_t mzmcts_rng_next_u32(mzmcts_rng *rng);
 double mzmcts_rng_random_sample(mzmcts_rng *rng);
 uint32_t mzmcts_rng_choice(mzmcts_rng *rng, uint32_t n);            /* numpy.random.choice(range(n)) */
 int32_t mzmcts_rng_choice_p(mzmcts_rng *rng, const double *p, int32_t n); /* choice(n, p=p) */
+/* choice(n, size=count, p=p): `count` draws in a row (replay_buffer.py:159 sample_n_games) */
+void mzmcts_rng_choice_p_many(mzmcts_rng *rng, const double *p, int32_t n, int32_t count, int32_t *out);
+/* ReplayBuffer.sample_position (replay_buffer.py:178-181): probs = priorities / sum(priorities) in float32,
+ * then choice(n, p=probs); *prob_out = probs[result] */
+int32_t mzmcts_rng_choice_priorities(mzmcts_rng *rng, const float *priorities, int32_t n, float *prob_out);
 void mzmcts_rng_dirichlet(mzmcts_rng *rng, double alpha, int32_t k, double *out);
 void mzmcts_rng_export(const mzmcts_rng *rng, uint32_t *key, int32_t *pos, int32_t *has_gauss,
                        double *cached_gaussian);

@@ -121,6 +121,8 @@ PROTOTYPES = {
     "mzmcts_rng_next_u32": (ctypes.c_uint32, [c_void]),
     "mzmcts_rng_random_sample": (ctypes.c_double, [c_void]),
     "mzmcts_rng_choice": (ctypes.c_uint32, [c_void, ctypes.c_uint32]),
+    "mzmcts_rng_choice_p_many": (None, [c_void, c_f64_p, ctypes.c_int32, ctypes.c_int32, c_i32_p]),
+    "mzmcts_rng_choice_priorities": (ctypes.c_int32, [c_void, c_f32_p, ctypes.c_int32, c_f32_p]),
     "mzmcts_rng_choice_p": (ctypes.c_int32, [c_void, c_f64_p, ctypes.c_int32]),
     "mzmcts_rng_dirichlet": (None, [c_void, ctypes.c_double, ctypes.c_int32, c_f64_p]),
     "mzmcts_rng_export": (None, [c_void, c_u32_p, c_i32_p, c_i32_p, c_f64_p]),
@@ -208,6 +210,19 @@ class HostRng:
     def choice_p(self, p):
         p = np.ascontiguousarray(p, dtype=np.float64)
         return self._lib.mzmcts_rng_choice_p(self._h, ptr(p, c_f64_p), len(p))
+
+    def choice_p_many(self, p, count):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        out = np.zeros(count, dtype=np.int32)
+        self._lib.mzmcts_rng_choice_p_many(self._h, ptr(p, c_f64_p), len(p), int(count), ptr(out, c_i32_p))
+        return out
+
+    def choice_priorities(self, priorities):
+        """(index, float32 probability) of choice(n, p=priorities / sum(priorities)) with float32 probabilities."""
+        pri = np.ascontiguousarray(priorities, dtype=np.float32)
+        prob = ctypes.c_float()
+        idx = self._lib.mzmcts_rng_choice_priorities(self._h, ptr(pri, c_f32_p), len(pri), ctypes.byref(prob))
+        return idx, np.float32(prob.value)
 
     def dirichlet(self, alpha, k):
         out = np.zeros(k, dtype=np.float64)

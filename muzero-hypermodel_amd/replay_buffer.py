@@ -167,7 +167,7 @@ class ReplayBuffer:
             game_probs = numpy.array([self.buffer[g]["game_priority"] for g in ids], dtype="float32")
             game_probs /= numpy.sum(game_probs)
             prob_of = dict(zip(ids, game_probs))
-            selected = [ids[self.rng.choice_p(game_probs)] for _ in range(n_games)]
+            selected = [ids[i] for i in self.rng.choice_p_many(game_probs, n_games)]
         else:
             prob_of = {}
             selected = [ids[self.rng.choice(len(ids))] for _ in range(n_games)]
@@ -176,9 +176,7 @@ class ReplayBuffer:
     def sample_position(self, entry, force_uniform=False):
         position_prob = None
         if self.config.PER and not force_uniform:
-            position_probs = entry["priorities"] / sum(entry["priorities"])
-            position_index = self.rng.choice_p(position_probs)
-            position_prob = position_probs[position_index]
+            position_index, position_prob = self.rng.choice_priorities(entry["priorities"])
         else:
             position_index = self.rng.choice(entry["length"])
         return position_index, position_prob

@@ -682,6 +682,32 @@ def g12_replay_targets(ctx):
         save(f"g12_replay_{name}", **out)
 
 
+def g12_reference_speed(ctx):
+    """How fast the reference builds training batches here (context for tools/replay_rate.py)."""
+    import copy
+    import replay_buffer
+    self_play, cfgs = ctx["self_play"], ctx["configs"]
+    config = copy.deepcopy(cfgs["cartpole"])
+    rs = numpy.random.RandomState(5)
+    games = [_synthetic_history(self_play, rs, config, int(n)) for n in rs.randint(50, 400, 200)]
+    rb = replay_buffer.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    t0 = time.perf_counter()
+    for gh in games:
+        rb.save_game(gh)
+    t_save = time.perf_counter() - t0
+    positions = sum(len(g.root_values) for g in games)
+    rb.get_batch()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        rb.get_batch()
+    t_batch = (time.perf_counter() - t0) / reps
+    print(f"   reference: save_game {positions / t_save:.0f} positions/s, get_batch {config.batch_size / t_batch:.0f} samples/s")
+    save("g12_reference_speed", save_game_positions_per_s=positions / t_save,
+         get_batch_samples_per_s=config.batch_size / t_batch, batch_size=config.batch_size,
+         games=len(games), positions=positions)
+
+
 def make_configs():
     import games.tictactoe as ttt
     import games.connect4 as c4
@@ -702,7 +728,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed]
 
 
 def main():
