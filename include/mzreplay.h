@@ -7,6 +7,10 @@
  *
  *   mzreplay_add_games      ReplayBuffer.save_game: initial priorities |root_value - target|^alpha and the
  *                           game priority (replay_buffer.py:33-50)
+ *   mzreplay_game_observations / mzreplay_set_reanalysed
+ *                           the two ends of Reanalyse's per-game step (replay_buffer.py:335-356): the stacked
+ *                           observations of every position of a game as one inference batch, and the fresh
+ *                           root values (float32) that compute_target_value bootstraps from afterwards
  *   mzreplay_make_batch     ReplayBuffer.make_target / compute_target_value and
  *                           GameHistory.get_stacked_observations for a batch of (game, position) pairs
  *                           (replay_buffer.py:222-295, self_play.py:514-548)
@@ -64,6 +68,14 @@ int mzreplay_add_games(mzreplay *store, int32_t n, const int32_t *slots, const i
 int mzreplay_make_batch(mzreplay *store, int32_t batch, const int32_t *slots, const int32_t *positions,
                         const int32_t *absorbing_actions, float *observations, int64_t *actions, double *values,
                         double *rewards, double *policies, double *gradient_scale, void *stream);
+
+/* Stacked observations of positions 0..length-1 of the game in `slot`: observations dev f32[length][C'][H][W].
+ * Asynchronous. */
+int mzreplay_game_observations(mzreplay *store, int32_t slot, int32_t length, float *observations, void *stream);
+/* Reanalyse's values for that game: f32[length], host or device memory.  From now on the game's targets
+ * bootstrap from them, accumulating in float32 as the reference does once the values are a numpy float32 array
+ * (NumPy >= 2 promotion; recorded in fixture G13).  mzreplay_add_games into the slot forgets them.  Asynchronous. */
+int mzreplay_set_reanalysed(mzreplay *store, int32_t slot, const float *values, int32_t length, void *stream);
 
 /* Bytes of device memory the store occupies. */
 int64_t mzreplay_device_bytes(const mzreplay *store);

@@ -107,6 +107,8 @@ PROTOTYPES = {
                                           c_f64_p, c_f64_p, c_f32_p, c_f32_p, c_void]),
     "mzreplay_make_batch": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_i32_p, c_i32_p, c_void, c_void, c_void,
                                            c_void, c_void, c_void, c_void]),
+    "mzreplay_game_observations": (ctypes.c_int, [c_void, ctypes.c_int32, ctypes.c_int32, c_void, c_void]),
+    "mzreplay_set_reanalysed": (ctypes.c_int, [c_void, ctypes.c_int32, c_void, ctypes.c_int32, c_void]),
     "mzreplay_device_bytes": (ctypes.c_int64, [c_void]),
     "mzenv_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_u32_p, ctypes.POINTER(c_void)]),
     "mzenv_destroy": (None, [c_void]),

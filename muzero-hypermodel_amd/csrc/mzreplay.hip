@@ -29,6 +29,8 @@ struct StoreParams {
     double* child_visits;
     double* root_values;
     int32_t* length;
+    float* reanalysed;           // [G][L] Reanalyse's fresh root values (float32, as the reference stores them)
+    uint8_t* has_reanalysed;     // [G]
     const double* discount_pow;  // [td_steps + 1]
 };
 
@@ -38,6 +40,20 @@ __device__ __forceinline__ double target_value(const StoreParams& p, int slot, i
     const int8_t* to_play = p.to_play + static_cast<size_t>(slot) * (p.L + 1);
     const int bootstrap = index + p.td_steps;
     double value = 0.0;
+    if (bootstrap < n && p.has_reanalysed[slot]) {
+        // reanalysed_predicted_root_values is a numpy float32 array (replay_buffer.py:226-231, 351-353): under
+        // NumPy 2 promotion the bootstrap product and every `value += python_float` stay float32
+        float last = p.reanalysed[static_cast<size_t>(slot) * p.L + bootstrap];
+        if (to_play[bootstrap] != to_play[index]) last = -last;
+        float v32 = last * static_cast<float>(p.discount_pow[p.td_steps]);
+        const int stop32 = bootstrap + 1 < n + 1 ? bootstrap + 1 : n + 1;
+        for (int k = index + 1, i = 0; k < stop32; ++k, ++i) {
+            const double r = rewards[k];
+            const double signed_r = (to_play[index] == to_play[index + i]) ? r : -r;
+            v32 = v32 + static_cast<float>(signed_r * p.discount_pow[i]);
+        }
+        return static_cast<double>(v32);
+    }
     if (bootstrap < n) {
         double last = p.root_values[static_cast<size_t>(slot) * p.L + bootstrap];
         if (to_play[bootstrap] != to_play[index]) last = -last;
@@ -76,6 +92,39 @@ __global__ __launch_bounds__(256) void priorities_kernel(StoreParams p, const in
         __syncthreads();
     }
     if (threadIdx.x == 0) game_priority[blockIdx.x] = block_max[0];
+}
+
+// GameHistory.get_stacked_observations (self_play.py:514-548) of one position, by the whole workgroup
+__device__ __forceinline__ void stacked_observation(const StoreParams& p, int slot, int pos, float* out) {
+    const int32_t* actions = p.actions + static_cast<size_t>(slot) * (p.L + 1);
+    const int plane = p.H * p.W;
+    const int out_channels = p.C + p.stacked * (p.C + 1);
+    const float* game_obs = p.obs + static_cast<size_t>(slot) * (p.L + 1) * p.obs_floats;
+    for (int t = threadIdx.x; t < out_channels * plane; t += blockDim.x) {
+        const int ch = t / plane, px = t - ch * plane;
+        float v;
+        if (ch < p.C) {
+            v = game_obs[static_cast<size_t>(pos) * p.obs_floats + t];
+        } else {
+            const int k = (ch - p.C) / (p.C + 1);        // k-th past frame: index pos - 1 - k
+            const int c = (ch - p.C) - k * (p.C + 1);    // its channel; c == C is the action plane
+            const int past = pos - 1 - k;
+            if (past < 0)
+                v = 0.f;
+            else if (c < p.C)
+                v = game_obs[static_cast<size_t>(past) * p.obs_floats + c * plane + px];
+            else
+                v = static_cast<float>(actions[past + 1]);
+        }
+        out[t] = v;
+    }
+}
+
+// every position of one game, stacked: the input batch of Reanalyse's initial_inference (replay_buffer.py:335-346)
+__global__ __launch_bounds__(128) void game_observations_kernel(StoreParams p, int slot, float* __restrict__ obs_out) {
+    const int pos = blockIdx.x;
+    if (pos >= p.length[slot]) return;
+    stacked_observation(p, slot, pos, obs_out + static_cast<size_t>(pos) * (p.C + p.stacked * (p.C + 1)) * p.H * p.W);
 }
 
 __global__ __launch_bounds__(128) void make_batch_kernel(StoreParams p, const int32_t* __restrict__ slots,
@@ -120,29 +169,7 @@ __global__ __launch_bounds__(128) void make_batch_kernel(StoreParams p, const in
         policies_out[static_cast<size_t>(b) * U1 * p.A + t] =
             cur < n ? p.child_visits[(static_cast<size_t>(slot) * p.L + cur) * p.A + a] : uniform;
     }
-    // ---- GameHistory.get_stacked_observations (self_play.py:514-548)
-    const int plane = p.H * p.W;
-    const int out_channels = p.C + p.stacked * (p.C + 1);
-    const float* game_obs = p.obs + static_cast<size_t>(slot) * (p.L + 1) * p.obs_floats;
-    float* out = obs_out + static_cast<size_t>(b) * out_channels * plane;
-    for (int t = threadIdx.x; t < out_channels * plane; t += blockDim.x) {
-        const int ch = t / plane, px = t - ch * plane;
-        float v;
-        if (ch < p.C) {
-            v = game_obs[static_cast<size_t>(pos) * p.obs_floats + t];
-        } else {
-            const int k = (ch - p.C) / (p.C + 1);        // k-th past frame: index pos - 1 - k
-            const int c = (ch - p.C) - k * (p.C + 1);    // its channel; c == C is the action plane
-            const int past = pos - 1 - k;
-            if (past < 0)
-                v = 0.f;
-            else if (c < p.C)
-                v = game_obs[static_cast<size_t>(past) * p.obs_floats + c * plane + px];
-            else
-                v = static_cast<float>(actions[past + 1]);
-        }
-        out[t] = v;
-    }
+    stacked_observation(p, slot, pos, obs_out + static_cast<size_t>(b) * (p.C + p.stacked * (p.C + 1)) * p.H * p.W);
 }
 
 }  // namespace
@@ -230,6 +257,8 @@ int mzreplay_create(const mzreplay_config* c, mzreplay** out) {
     rc |= dev_alloc(s, &p.child_visits, G * L * p.A);
     rc |= dev_alloc(s, &p.root_values, G * L);
     rc |= dev_alloc(s, &p.length, G);
+    rc |= dev_alloc(s, &p.reanalysed, G * L);
+    rc |= dev_alloc(s, &p.has_reanalysed, G);
     rc |= dev_alloc(s, &d_pow, static_cast<size_t>(p.td_steps) + 1);
     if (rc || hipMemcpy(d_pow, c->discount_powers, sizeof(double) * (p.td_steps + 1), hipMemcpyHostToDevice) != hipSuccess) {
         const std::string msg = s->error.empty() ? "mzreplay_create: device allocation failed" : s->error;
@@ -286,6 +315,7 @@ int mzreplay_add_games(mzreplay* s, int32_t n, const int32_t* slots, const int32
         RP_HIP(s, hipMemcpyAsync(p.root_values + slot * L, root_values + static_cast<size_t>(g) * L, sizeof(double) * len,
                                  hipMemcpyHostToDevice, stream));
         RP_HIP(s, hipMemcpyAsync(p.length + slot, lengths + g, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        RP_HIP(s, hipMemsetAsync(p.has_reanalysed + slot, 0, 1, stream));
     }
     RP_HIP(s, hipMemcpyAsync(s->d_slots, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice, stream));
     priorities_kernel<<<dim3(n), dim3(256), 0, stream>>>(s->p, s->d_slots, s->d_priorities, s->d_game_priority);
@@ -295,6 +325,24 @@ int mzreplay_add_games(mzreplay* s, int32_t n, const int32_t* slots, const int32
     if (game_priority)
         RP_HIP(s, hipMemcpyAsync(game_priority, s->d_game_priority, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
     RP_HIP(s, hipStreamSynchronize(stream));
+    return 0;
+}
+
+int mzreplay_game_observations(mzreplay* s, int32_t slot, int32_t length, float* observations, void* stream_) {
+    if (!s || !observations || slot < 0 || slot >= s->p.G || length < 1 || length > s->p.L)
+        return fail(s, "mzreplay_game_observations: bad argument");
+    game_observations_kernel<<<dim3(length), dim3(128), 0, static_cast<hipStream_t>(stream_)>>>(s->p, slot, observations);
+    RP_HIP(s, hipGetLastError());
+    return 0;
+}
+
+int mzreplay_set_reanalysed(mzreplay* s, int32_t slot, const float* values, int32_t length, void* stream_) {
+    if (!s || !values || slot < 0 || slot >= s->p.G || length < 1 || length > s->p.L)
+        return fail(s, "mzreplay_set_reanalysed: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    RP_HIP(s, hipMemcpyAsync(s->p.reanalysed + static_cast<size_t>(slot) * s->p.L, values, sizeof(float) * length,
+                             hipMemcpyDefault, stream));
+    RP_HIP(s, hipMemsetAsync(s->p.has_reanalysed + slot, 1, 1, stream));
     return 0;
 }
 

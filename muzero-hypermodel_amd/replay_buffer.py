@@ -227,6 +227,28 @@ class ReplayBuffer:
         self._keep = (slots, positions, absorbing)
         return out
 
+    # ---- Reanalyse's two ends (replay_buffer.py:335-356) ------------------------------------------------
+    def game_observations(self, game_id):
+        """Stacked observations of every position of a stored game: CUDA tensor [n, C', H, W]."""
+        n = self.buffer[game_id]["length"]
+        stacked = int(self.config.stacked_observations)
+        out = torch.empty((n, self.C + stacked * (self.C + 1), self.H, self.W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.mzreplay_game_observations(self._h, self._slot(game_id), n, out.data_ptr(), self._stream()))
+        return out
+
+    def set_reanalysed_values(self, game_id, values):
+        """game_history.reanalysed_predicted_root_values = values (float32 [n], tensor or array)."""
+        if game_id not in self.buffer:      # the game could have been removed since its selection
+            return
+        n = self.buffer[game_id]["length"]
+        v = torch.as_tensor(values, dtype=torch.float32).reshape(-1).contiguous()
+        assert v.numel() == n
+        self._keep_values = v
+        with torch.cuda.device(self.device):
+            self._check(self._lib.mzreplay_set_reanalysed(self._h, self._slot(game_id), v.data_ptr(), n, self._stream()))
+        self.buffer[game_id]["reanalysed"] = True
+
     # ---- priorities (replay_buffer.py:197-220) ---------------------------------------------------------
     def update_priorities(self, priorities, index_info):
         for i in range(len(index_info)):
@@ -238,3 +260,45 @@ class ReplayBuffer:
                 end_index = min(game_pos + len(priority), len(entry["priorities"]))
                 entry["priorities"][start_index:end_index] = priority[: end_index - start_index]
                 entry["game_priority"] = numpy.max(entry["priorities"])
+
+
+class Reanalyse:
+    """Reanalyse (reference replay_buffer.py:297-361) against the device store: one batched initial_inference
+    over all positions of a sampled game, support_to_scalar, values written back into the store."""
+
+    def __init__(self, initial_checkpoint, config, device=None):
+        from . import models
+        self._models = models
+        self.config = config
+        torch.manual_seed(self.config.seed)
+        self.device = torch.device(device if device is not None else "cuda")
+        self.model = models.MuZeroNetwork(self.config)
+        self.model.set_weights(initial_checkpoint["weights"])
+        self.model.to(self.device)
+        self.model.eval()
+        self.num_reanalysed_games = initial_checkpoint.get("num_reanalysed_games", 0)
+
+    @torch.no_grad()
+    def reanalyse_game(self, replay_buffer, game_id=None):
+        """One pass of the reference's loop body; returns (game_id, values tensor)."""
+        if game_id is None:
+            game_id, _, _ = replay_buffer.sample_game(force_uniform=True)
+        values = None
+        if self.config.use_last_model_value:
+            observations = replay_buffer.game_observations(game_id)
+            values = self._models.support_to_scalar(self.model.initial_inference(observations)[0], self.config.support_size)
+            values = values.reshape(-1).float()
+            replay_buffer.set_reanalysed_values(game_id, values)
+        self.num_reanalysed_games += 1
+        return game_id, values
+
+    def reanalyse(self, replay_buffer, shared_storage, max_games=None):
+        """The reference's loop without Ray: runs until shared_storage reports the end of training."""
+        done = 0
+        while shared_storage.get_info("training_step") < self.config.training_steps and not shared_storage.get_info("terminate"):
+            self.model.set_weights(shared_storage.get_info("weights"))
+            self.reanalyse_game(replay_buffer)
+            shared_storage.set_info("num_reanalysed_games", self.num_reanalysed_games)
+            done += 1
+            if max_games is not None and done >= max_games:
+                break

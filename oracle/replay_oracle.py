@@ -9,8 +9,9 @@ uses float32):
     make_target             ReplayBuffer.make_target                replay_buffer.py:258-295
     stacked_observations    GameHistory.get_stacked_observations    self_play.py:514-548
     sample_* / get_batch    ReplayBuffer.get_batch and its samplers replay_buffer.py:67-195
+    (reanalysed values)     Reanalyse.reanalyse's per-game step     replay_buffer.py:335-356, 226-231
 
-PINNED against fixtures G12 (tests/golden/g12_replay_*.npz), recorded by running the reference's own
+PINNED against fixtures G12 / G13 (tests/golden/g12_replay_*.npz, g13_reanalyse_cartpole.npz), recorded by running the reference's own
 ReplayBuffer on synthetic game histories (tests/golden/make_golden.py:g12_replay_targets).  Random draws go
 through mz_oracle.Rng, the numpy legacy RandomState clone pinned by fixture G7.  Only tests/ may import this.
 """
@@ -29,12 +30,15 @@ class Game:
         self.root_values = [float(v) for v in root_values]
         self.priorities = None
         self.game_priority = None
+        self.reanalysed = None          # numpy float32 array once Reanalyse has visited the game
 
 
 def compute_target_value(game, index, td_steps, discount):
     bootstrap = index + td_steps
     if bootstrap < len(game.root_values):
-        last = game.root_values[bootstrap]
+        # reanalysed values are numpy float32 scalars: under NumPy 2 promotion the whole sum then runs in
+        # float32 (Python floats are weak), which is what fixture G13 records
+        last = (game.root_values if game.reanalysed is None else game.reanalysed)[bootstrap]
         if game.to_play[bootstrap] != game.to_play[index]:
             last = -last
         value = last * discount ** td_steps

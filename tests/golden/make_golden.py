@@ -682,6 +682,69 @@ def g12_replay_targets(ctx):
         save(f"g12_replay_{name}", **out)
 
 
+def g13_reanalyse(ctx):
+    """Reanalyse's per-game step (replay_buffer.py:335-356) -- stacked observations of every position, one
+    batched initial_inference, support_to_scalar -- and the targets ReplayBuffer.make_target builds once a game
+    carries reanalysed_predicted_root_values (replay_buffer.py:226-231: numpy float32 scalars from then on)."""
+    import copy
+    import replay_buffer
+    models, self_play, cfgs = ctx["models"], ctx["self_play"], ctx["configs"]
+    config = copy.deepcopy(cfgs["cartpole"])
+    model = build_model(models, config, load_cartpole_checkpoint())
+    rs = numpy.random.RandomState(99)
+    lengths = [int(v) for v in rs.randint(5, 120, 6)]
+    games = [_synthetic_history(self_play, rs, config, n) for n in lengths]
+    for gh in games:                       # observations the network can digest: small, like CartPole states
+        gh.observation_history = [numpy.float32(0.05) * o for o in gh.observation_history]
+    rb = replay_buffer.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    for gh in games:
+        rb.save_game(gh)
+    L, A, G = max(lengths), len(config.action_space), len(games)
+    reanalysed = numpy.zeros((G, L), dtype="float32")
+    for g, gh in enumerate(games):
+        observations = [gh.get_stacked_observations(i, config.stacked_observations) for i in range(len(gh.root_values))]
+        observations = torch.tensor(numpy.array(observations)).float()
+        with torch.no_grad():
+            values = models.support_to_scalar(model.initial_inference(observations)[0], config.support_size)
+        gh.reanalysed_predicted_root_values = torch.squeeze(values).detach().cpu().numpy()
+        reanalysed[g, : lengths[g]] = gh.reanalysed_predicted_root_values
+        rb.update_game_history(g, gh)
+    pairs, values, rewards, policies, actions = [], [], [], [], []
+    numpy.random.seed(1234)
+    for g, gh in enumerate(games):
+        for pos in sorted(set([0, lengths[g] // 3, lengths[g] - 2, lengths[g] - 1])):
+            if pos < 0:
+                continue
+            v, r, p, a = rb.make_target(rb.buffer[g], pos)
+            pairs.append([g, pos])
+            values.append([float(x) for x in v])
+            rewards.append([float(x) for x in r])
+            policies.append(p)
+            actions.append(a)
+    out = dict(config_scalars(config))
+    obs = numpy.zeros((G, L + 1) + tuple(config.observation_shape), dtype="float32")
+    act = numpy.zeros((G, L + 1), dtype="int32")
+    rew = numpy.zeros((G, L + 1), dtype="float64")
+    tp = numpy.zeros((G, L + 1), dtype="int32")
+    cv = numpy.zeros((G, L, A), dtype="float64")
+    rv = numpy.zeros((G, L), dtype="float64")
+    for g, gh in enumerate(games):
+        n = lengths[g]
+        obs[g, : n + 1] = numpy.array(gh.observation_history)
+        act[g, : n + 1] = gh.action_history
+        rew[g, : n + 1] = gh.reward_history
+        tp[g, : n + 1] = gh.to_play_history
+        cv[g, :n] = gh.child_visits
+        rv[g, :n] = gh.root_values
+    out.update(lengths=numpy.array(lengths, dtype="int32"), observations=obs, actions=act, rewards=rew, to_play=tp,
+               child_visits=cv, root_values=rv, reanalysed=reanalysed, pairs=numpy.array(pairs, dtype="int32"),
+               value_targets=numpy.array(values, dtype="float64"), reward_targets=numpy.array(rewards, dtype="float64"),
+               policy_targets=numpy.array(policies, dtype="float64"), action_targets=numpy.array(actions, dtype="int64"),
+               td_steps=config.td_steps, num_unroll_steps=config.num_unroll_steps, seed=1234,
+               numpy_version=numpy.array(numpy.__version__))
+    save("g13_reanalyse_cartpole", **out)
+
+
 def g12_reference_speed(ctx):
     """How fast the reference builds training batches here (context for tools/replay_rate.py)."""
     import copy
@@ -728,7 +791,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse]
 
 
 def main():

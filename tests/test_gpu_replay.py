@@ -112,3 +112,37 @@ def test_replay_store_ring_and_priority_updates(pkg):
     n = rb.buffer[gid]["length"]
     assert (rb.buffer[gid]["priorities"][pos: min(n, pos + 11)] == 7.5).all() and rb.buffer[gid]["game_priority"] == 7.5
     rb.close()
+
+
+def test_reanalyse_values_and_targets(pkg):
+    """Reanalyse on the device store vs fixture G13 (the reference's per-game step and the targets built on top)."""
+    from parity_helpers import cartpole_model_and_weights
+    rb_mod = importlib.import_module("muzero-hypermodel_amd.replay_buffer")
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    fx = load_golden("g13_reanalyse_cartpole")
+    config = importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
+    _, weights = cartpole_model_and_weights(models_mod, config, "cpu")
+    G = len(fx["lengths"])
+    rb = rb_mod.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    for g in range(G):
+        rb.save_game(history_of(sp, fx, g))
+    re = rb_mod.Reanalyse({"weights": weights, "num_reanalysed_games": 0}, config)
+    for g in range(G):
+        n = int(fx["lengths"][g])
+        assert np.array_equal(rb.game_observations(g).cpu().numpy().reshape(n, -1),
+                              fx["observations"][g, :n].reshape(n, -1))          # stacked_observations == 0 here
+        gid, values = re.reanalyse_game(rb, g)
+        want = fx["reanalysed"][g, :n]
+        np.testing.assert_allclose(values.cpu().numpy(), want, rtol=3e-5, atol=1e-5)   # fp32 network, decoded values
+        rb.set_reanalysed_values(g, want)      # the reference's own values: the targets below compare bit for bit
+    assert re.num_reanalysed_games == G
+    slots = fx["pairs"][:, 0].astype(np.int32)
+    positions = fx["pairs"][:, 1].astype(np.int32)
+    out = rb.make_targets(slots, positions, fx["action_targets"].astype(np.int32))
+    assert np.array_equal(out["value"].cpu().numpy(), fx["value_targets"])       # float32 accumulation where bootstrapped
+    assert np.array_equal(out["reward"].cpu().numpy(), fx["reward_targets"])
+    assert np.array_equal(out["policy"].cpu().numpy(), fx["policy_targets"])
+    assert np.array_equal(out["action"].cpu().numpy(), fx["action_targets"])
+    rb.save_game(history_of(sp, fx, 0))        # a new game in a reanalysed slot forgets the old values
+    rb.close()

@@ -49,3 +49,19 @@ def test_replay_oracle_matches_reference(oracle, name):
     assert np.array_equal(np.array(out["observation"], dtype=np.float32), fx["observation_batch"])
     if cfg["PER"]:
         assert np.array_equal(out["weight"], fx["weight_batch"])
+
+
+def test_replay_oracle_with_reanalysed_values(oracle):
+    ro = importlib.import_module("replay_oracle")
+    fx = load_golden("g13_reanalyse_cartpole")
+    games = games_of(fx, ro)
+    for g, game in enumerate(games):
+        game.reanalysed = fx["reanalysed"][g, : len(game.root_values)].copy()
+    rng = oracle.Rng(int(fx["seed"]))
+    for i, (g, pos) in enumerate(fx["pairs"]):
+        v, r, p, a = ro.make_target(games[g], int(pos), int(fx["td_steps"]), float(fx["cfg_discount"]),
+                                    int(fx["num_unroll_steps"]), list(range(int(fx["cfg_A"]))), rng)
+        assert np.array_equal(np.array([float(x) for x in v]), fx["value_targets"][i]), (g, pos)
+        assert np.array_equal(np.array(r, dtype=np.float64), fx["reward_targets"][i])
+        assert np.array_equal(np.array(p, dtype=np.float64), fx["policy_targets"][i])
+        assert np.array_equal(np.array(a), fx["action_targets"][i])
