@@ -745,6 +745,44 @@ def g13_reanalyse(ctx):
     save("g13_reanalyse_cartpole", **out)
 
 
+def g14_trainer(ctx):
+    """Trainer.update_lr / update_weights (trainer.py:124-298) for two steps on one ReplayBuffer batch, starting
+    from the CartPole checkpoint: losses, new priorities and the weights after each step."""
+    import copy
+    import replay_buffer
+    import trainer
+    self_play, cfgs = ctx["self_play"], ctx["configs"]
+    config = copy.deepcopy(cfgs["cartpole"])
+    config.batch_size = 32
+    config.train_on_gpu = False
+    rs = numpy.random.RandomState(314)
+    lengths = [int(v) for v in rs.randint(8, 90, 12)]
+    games = [_synthetic_history(self_play, rs, config, n) for n in lengths]
+    for gh in games:
+        gh.observation_history = [numpy.float32(0.05) * o for o in gh.observation_history]
+    rb = replay_buffer.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    for gh in games:
+        rb.save_game(gh)
+    index_batch, batch = rb.get_batch()
+    weights = load_cartpole_checkpoint()
+    tr = trainer.Trainer({"weights": copy.deepcopy(weights), "training_step": 0, "optimizer_state": None}, config)
+    out = dict(config_scalars(config))
+    obs_b, act_b, val_b, rew_b, pol_b, w_b, gs_b = batch
+    out.update(observation_batch=numpy.array(obs_b, dtype="float32"), action_batch=numpy.array(act_b, dtype="int64"),
+               value_batch=numpy.array(val_b, dtype="float64"), reward_batch=numpy.array(rew_b, dtype="float64"),
+               policy_batch=numpy.array(pol_b, dtype="float64"), weight_batch=numpy.array(w_b, dtype="float32"),
+               gradient_scale_batch=numpy.array(gs_b, dtype="float64"))
+    for step in range(2):
+        tr.update_lr()
+        out[f"lr{step}"] = tr.optimizer.param_groups[0]["lr"]
+        priorities, total, v, r, p = tr.update_weights(batch)
+        out[f"priorities{step}"] = numpy.asarray(priorities, dtype="float32")
+        out[f"losses{step}"] = numpy.array([total, v, r, p], dtype="float64")
+        for k, t in tr.model.get_weights().items():
+            out[f"w{step}_{k}"] = t.detach().cpu().numpy().copy()   # (get_weights aliases the live parameters)
+    save("g14_trainer_cartpole", **out)
+
+
 def g12_reference_speed(ctx):
     """How fast the reference builds training batches here (context for tools/replay_rate.py)."""
     import copy
@@ -791,7 +829,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer]
 
 
 def main():

@@ -146,3 +146,24 @@ def test_reanalyse_values_and_targets(pkg):
     assert np.array_equal(out["action"].cpu().numpy(), fx["action_targets"])
     rb.save_game(history_of(sp, fx, 0))        # a new game in a reanalysed slot forgets the old values
     rb.close()
+
+
+def test_trainer_on_device_matches_reference(pkg):
+    """Trainer.update_weights on the MI355X from CUDA-tensor batches vs the reference's CPU run (fixture G14)."""
+    from test_trainer_cpu import run_steps
+    fx = load_golden("g14_trainer_cartpole")
+    tr, out = run_steps(pkg, fx, "cuda", True)
+    assert next(tr.model.parameters()).is_cuda
+    for step, (lr, priorities, losses, weights) in enumerate(out):
+        assert lr == float(fx[f"lr{step}"])
+        np.testing.assert_allclose(losses, fx[f"losses{step}"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(priorities, fx[f"priorities{step}"], rtol=2e-3, atol=2e-3)
+        # Adam's first steps move every weight by ~lr * sign(gradient): a gradient that is zero up to rounding may
+        # flip its sign between the CPU and the GPU kernels, so compare entry-wise with that in mind
+        close = total = 0
+        for k, got in weights.items():
+            diff = np.abs(got - fx[f"w{step}_{k}"])
+            assert diff.max() <= 2.1 * lr * (step + 1), k
+            close += int((diff <= 1e-4).sum())
+            total += diff.size
+        assert close >= 0.97 * total, f"{close}/{total} weights agree after step {step}"
