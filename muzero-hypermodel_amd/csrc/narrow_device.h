@@ -350,14 +350,16 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
         const unsigned long long ballot = __ballot(is_max);
         unsigned int mask = static_cast<unsigned int>(ballot >> group_base) & ((1u << SPAN) - 1u);
         const int n_ties = __popc(mask);
-        if (n_ties > 1) {  // numpy.random.choice over the tie list (self_play.py:372-378)
-            int r = 0;
-            if (j == 0) r = static_cast<int>(mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words));
-            r = row_or(r);
-            for (int i = 0; i < r; ++i) mask &= mask - 1u;
-        } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
-            if (j == 0) atomicOr(error_flag, 1);
-            mask = 1u;
+        if (n_ties != 1) {
+            if (n_ties > 1) {  // numpy.random.choice over the tie list (self_play.py:372-378)
+                int r = 0;
+                if (j == 0) r = static_cast<int>(mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words));
+                r = row_or(r);
+                for (int i = 0; i < r; ++i) mask &= mask - 1u;
+            } else {  // NaN scores: the reference would raise; flag and take slot 0
+                if (j == 0) atomicOr(error_flag, 1);
+                mask = 1u;
+            }
         }
         slot = __ffs(static_cast<int>(mask)) - 1;
         MZ_DSTAMP(10);
