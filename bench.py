@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="envs (trees) per GPU")
-    ap.add_argument("--bcast-every", type=int, default=25, help="weight broadcast period in steps (N>1)")
+    ap.add_argument("--bcast-every", type=int, default=50, help="weight broadcast period in steps (N>1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
     ap.add_argument("--groups", type=int, default=2,
                     help="fused mode with --moves-per-batch 0: env groups per GPU on separate HIP streams")
-    ap.add_argument("--moves-per-batch", type=int, default=25,
+    ap.add_argument("--moves-per-batch", type=int, default=50,
                     help="fused mode: moves queued back to back per host round trip (mzmcts_moves_*); "
                          "0 = one host round trip per move, pipelined over --groups env groups")
     return ap.parse_args()

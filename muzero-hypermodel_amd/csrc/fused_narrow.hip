@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "fc_net_device.h"
 #include "kernel_common.h"
 #include "narrow_device.h"
@@ -42,6 +45,8 @@ bool narrow_supported(const TreeParams& p, const FcNet& net) {
 // SIMD); second pass: anything that fits a workgroup's 160 KB.  Returns false when nothing does.
 bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit, NarrowLayout* out) {
     auto align16 = [](size_t v) { return (v + 15) / 16 * 16; };
+    int rows = 4;
+    if (const char* env = std::getenv("MZMCTS_NARROW_ROWS")) rows = std::max(1, std::min(4, std::atoi(env)));
     for (int pass = 0; pass < 2; ++pass)
     for (int with_pbc2 = 1; with_pbc2 >= 0; --with_pbc2) {
         for (int waves = 4; waves >= 1; waves >>= 1) {
@@ -71,10 +76,11 @@ bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit,
             t = align16(t + 4 * 2 * kRow);
             lay.tree_bytes = static_cast<uint32_t>(t);
             lay.waves = waves;
-            const size_t total = off + static_cast<size_t>(waves) * 4 * t;
+            lay.rows = rows;
+            const size_t total = off + static_cast<size_t>(waves) * rows * t;
             lay.total_bytes = static_cast<uint32_t>(total);
-            // pass 0: 4/waves workgroups share a CU's LDS
-            if (total <= (pass == 0 ? lds_limit * waves / 4 : lds_limit)) {
+            // pass 0: a CU keeps 16 trees resident: 16 / (waves * rows) workgroups share its LDS
+            if (total <= (pass == 0 ? lds_limit * waves * rows / 16 : lds_limit)) {
                 *out = lay;
                 return true;
             }
@@ -125,10 +131,12 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
     __syncthreads();
     MZ_STAMP(0);
 
-    const int tree_in_block = threadIdx.x / kRow;
-    const int e = blockIdx.x * (blockDim.x / kRow) + tree_in_block;
     const int j = threadIdx.x % kRow;
     const int group_base = (threadIdx.x & 63) - j;  // lane of the row's first lane inside its wavefront
+    const int row = group_base / kRow;
+    if (row >= lay.rows) return;                    // this wavefront carries fewer than four trees
+    const int tree_in_block = (threadIdx.x / 64) * lay.rows + row;
+    const int e = blockIdx.x * (blockDim.x / 64) * lay.rows + tree_in_block;
     if (e >= p.E) return;
     const int n_root = p.root_children[e];
     if (move_stalled(p, ctl, e, j)) return;
@@ -312,7 +320,7 @@ static hipError_t launch_narrow_span(const TreeParams& p, const FcNet& net, cons
                                      const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
                                      hipStream_t stream, const LaunchTiming* timing) {
     const int threads = 64 * lay.waves;
-    const int trees = threads / kRow;
+    const int trees = lay.waves * lay.rows;
     const int grid = (p.E + trees - 1) / trees;
     auto go = [&](auto kernel) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),

@@ -83,7 +83,7 @@ struct EventPair {
 class WorkerPool {
   public:
     explicit WorkerPool(int workers) {
-        for (int i = 0; i < workers; ++i) threads_.emplace_back([this, i] { loop(i); });
+        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
     }
     ~WorkerPool() {
         {
@@ -95,28 +95,46 @@ class WorkerPool {
         for (auto& t : threads_) t.join();
     }
     int size() const { return static_cast<int>(threads_.size()); }
-    // body(lo, hi) over [0, n) split into size()+1 contiguous chunks; the caller runs the last one.
+    // body(lo, hi) over [0, n) in small chunks claimed dynamically by the workers and the caller.  The job is
+    // complete when every CHUNK is done, not when every worker has reported: on a busy host a worker that is
+    // descheduled (or still asleep) delays nothing it has not claimed.
     void run(int n, const std::function<void(int, int)>& body) {
         std::lock_guard<std::mutex> serial(run_mu_);  // one job at a time (engines share the pool)
-        const int parts = size() + 1;
-        const int chunk = (n + parts - 1) / parts;
+        const int per_thread = 4;
+        int chunk = n / ((size() + 1) * per_thread);
+        if (chunk < 16) chunk = 16;
+        const uint64_t g = generation_.load(std::memory_order_relaxed) + 1;
         body_ = &body;
         n_ = n;
         chunk_ = chunk;
-        pending_.store(size(), std::memory_order_relaxed);
+        total_ = (n + chunk - 1) / chunk;
+        done_.store(0, std::memory_order_relaxed);
+        next_.store(g << 32, std::memory_order_release);  // publishes the fields above for generation g
         {
             std::lock_guard<std::mutex> lock(mu_);
-            generation_.fetch_add(1, std::memory_order_release);
+            generation_.store(g, std::memory_order_release);
         }
         cv_.notify_all();
-        const int lo = size() * chunk;
-        if (lo < n) body(lo, n);
-        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        work(g);
+        while (done_.load(std::memory_order_acquire) < total_) __builtin_ia32_pause();
         body_ = nullptr;
     }
 
   private:
-    void loop(int index) {
+    // claim chunks of generation g until none is left (or the job has moved on)
+    void work(uint64_t g) {
+        for (;;) {
+            uint64_t cur = next_.load(std::memory_order_acquire);
+            if ((cur >> 32) != g) return;
+            const int idx = static_cast<int>(cur & 0xffffffffu);
+            if (idx >= total_) return;  // (fields belong to generation g: they were written before next_ carried g)
+            if (!next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
+            const int lo = idx * chunk_, hi = std::min(n_, lo + chunk_);
+            (*body_)(lo, hi);  // the job cannot complete (and the fields cannot change) before this chunk is counted
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop() {
         uint64_t seen = 0;
         for (;;) {
             // spin for the next job, then fall back to sleeping
@@ -134,18 +152,16 @@ class WorkerPool {
             }
             seen = generation_.load(std::memory_order_acquire);
             if (stop_) return;
-            const std::function<void(int, int)>* body = body_;
-            const int lo = index * chunk_, hi = std::min(n_, lo + chunk_);
-            if (body && lo < hi) (*body)(lo, hi);
-            pending_.fetch_sub(1, std::memory_order_release);
+            work(seen);
         }
     }
     std::vector<std::thread> threads_;
     std::mutex mu_, run_mu_;
     std::condition_variable cv_;
     const std::function<void(int, int)>* body_ = nullptr;
-    int n_ = 0, chunk_ = 0;
-    std::atomic<int> pending_{0};
+    int n_ = 0, chunk_ = 0, total_ = 0;
+    std::atomic<int> done_{0};
+    std::atomic<uint64_t> next_{0};
     std::atomic<uint64_t> generation_{0};
     bool stop_ = false;
 };

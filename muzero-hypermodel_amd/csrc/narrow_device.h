@@ -56,7 +56,8 @@ struct NarrowLayout {
     uint32_t off_hidden;   // float[(S+1)][enc]
     uint32_t off_misc;     // int32[16] root actions | float[16] root policy logits
     uint32_t total_bytes;
-    int32_t waves;         // wavefronts (= 4 trees each) per workgroup
+    int32_t waves;         // wavefronts per workgroup
+    int32_t rows;          // trees (16-lane rows) a wavefront carries: 4, or fewer to cut the wait for its deepest tree
 };
 
 template <int R>
