@@ -131,17 +131,27 @@ def main():
             draws a batch's exploration noise while the previous batch runs and collects actions / visit counts /
             root values of a batch when it is done; kernels of one batch follow each other without host round
             trips.  trailing_predraw = (moves) draws one more batch during the last one (left uploaded-ready)."""
+            trace = os.environ.get("MZ_BENCH_TRACE")
             for n, (i, b) in enumerate(plan):
                 if world > 1 and args.bcast_every and i % args.bcast_every == 0:
                     actor.refresh_weights(src=0)
+                t = [time.perf_counter()]
                 for k in range(b):
                     engine.moves_enqueue(flat_obs[(i + k) % len(flat_obs)])
+                t.append(time.perf_counter())
                 nxt = plan[n + 1][1] if n + 1 < len(plan) else trailing_predraw
                 if nxt:
                     engine.moves_predraw_next(nxt, legal, to_play, temperature, True, num_legal=num_legal)
-                engine.moves_collect()
+                t.append(time.perf_counter())
+                out = engine.moves_collect(copy=bool(os.environ.get("MZ_BENCH_COPY")))   # default: views of the download ring
+                t.append(time.perf_counter())
                 if n + 1 < len(plan):
                     engine.moves_submit_next()
+                t.append(time.perf_counter())
+                if trace:
+                    print(f"[bench] batch of {b}: enqueue {1e3 * (t[1] - t[0]):.2f} ms, predraw {1e3 * (t[2] - t[1]):.2f}, "
+                          f"collect {1e3 * (t[3] - t[2]):.2f}, submit {1e3 * (t[4] - t[3]):.2f}; moves done min "
+                          f"{int(out['moves_done'].min())}", file=sys.stderr, flush=True)
     elif fused and args.groups > 1:
         # n env groups on n streams: one group's host work overlaps the other groups' kernels
         n = args.groups

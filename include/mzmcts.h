@@ -280,6 +280,12 @@ int mzmcts_moves_enqueue(mzmcts_engine *engine, const float *observations, void 
 const int32_t *mzmcts_moves_actions(mzmcts_engine *engine, int32_t move);
 int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *actions, int32_t *visits,
                          double *root_value_sum, float *root_predicted, int32_t *max_depth, void *stream);
+/* Zero-copy access to what collect downloads: the pinned host ring holds one block per move, `move_stride`
+ * bytes apart, with actions i32[E], visits i32[E][A], root_value_sum f64[E], root_predicted f32[E], max_depth
+ * i32[E] at offsets[0..4]; the ring holds capacity_moves blocks.  Valid from a collect until the next one; entries of env e in moves >=
+ * moves_done[e] are undefined (its action reads -1 in the first such move). */
+int mzmcts_moves_ring(mzmcts_engine *engine, void **host_base, int64_t *move_stride, int64_t *offsets,
+                      int32_t *capacity_moves);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mzmcts_moves_discard_next": (ctypes.c_int, [c_void]),
     "mzmcts_moves_enqueue": (ctypes.c_int, [c_void, c_void, c_void]),
     "mzmcts_moves_actions": (c_void, [c_void, ctypes.c_int32]),
+    "mzmcts_moves_ring": (ctypes.c_int, [c_void, ctypes.POINTER(c_void), c_i64_p, c_i64_p, c_i32_p]),
     "mzmcts_moves_collect": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_f64_p, c_f32_p, c_i32_p, c_void]),
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),

@@ -116,7 +116,7 @@ __device__ __forceinline__ void stage_narrow_tables(const TreeParams& p, const N
 // one launch per move: root inference + expansion + noise, S simulations, publish
 // -------------------------------------------------------------------------------------------------
 template <int SPAN, bool PBC2>
-__global__ __launch_bounds__(kNarrowMaxThreads) void search_fused_narrow_kernel(
+__global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_fused_narrow_kernel(
     TreeParams p, FcNet net, NarrowLayout lay, const float* __restrict__ weights,
     const float* __restrict__ observations,  // [E][obs]
     MoveCtl ctl, int n_sims, int publish_tree) {

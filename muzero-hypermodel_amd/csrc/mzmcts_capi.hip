@@ -1281,6 +1281,10 @@ static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
         c.deferred.assign(E, 0);
     }
     b.capacity = n_moves;
+    // Run both transfers once at full size: the runtime sets up its large-copy path on first use (tens of
+    // milliseconds), which would otherwise land in the first full-size batch.
+    MZ_HIP(eng, hipMemcpy(b.d_in, b.set[0].h_in, b.in_bytes, hipMemcpyHostToDevice));
+    MZ_HIP(eng, hipMemcpy(b.h_out, b.d_out, b.out_stride * M, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1520,6 +1524,21 @@ const int32_t* mzmcts_moves_actions(mzmcts_engine* eng, int32_t move) {
                                             eng->batch.o_actions);
 }
 
+int mzmcts_moves_ring(mzmcts_engine* eng, void** host_base, int64_t* move_stride, int64_t* offsets, int32_t* capacity) {
+    if (!eng || !host_base || !move_stride || !offsets || !capacity) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.h_out) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_ring: no batch has been prepared yet");
+    *host_base = b.h_out;
+    *move_stride = static_cast<int64_t>(b.out_stride);
+    *capacity = b.capacity;
+    offsets[0] = static_cast<int64_t>(b.o_actions);
+    offsets[1] = static_cast<int64_t>(b.o_visits);
+    offsets[2] = static_cast<int64_t>(b.o_rvs);
+    offsets[3] = static_cast<int64_t>(b.o_pred);
+    offsets[4] = static_cast<int64_t>(b.o_depth);
+    return MZMCTS_OK;
+}
+
 int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actions, int32_t* visits, double* root_value_sum,
                          float* root_predicted, int32_t* max_depth, void* stream_) {
     if (!eng) return MZMCTS_ERR_INVALID;
@@ -1527,10 +1546,17 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
     if (!b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_collect: no batch in flight");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int E = eng->p.E, A = eng->p.A, M = b.enqueued;
+    const bool trace = std::getenv("MZMCTS_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = trace ? now() : 0.0;
+    MZ_HIP(eng, hipEventRecord(b.done, stream));
+    MZ_HIP(eng, hipEventSynchronize(b.done));
+    const double t_kernels = trace ? now() : 0.0;
     if (M > 0) MZ_HIP(eng, hipMemcpyAsync(b.h_out, b.d_out, b.out_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, eng->p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipEventRecord(b.done, stream));
     MZ_HIP(eng, hipEventSynchronize(b.done));
+    const double t_copied = trace ? now() : 0.0;
     b.in_flight = false;
     ChainSet& c = b.set[b.cur];
     ChainSet& next = b.set[b.cur ^ 1];
@@ -1598,6 +1624,9 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
         depth_total.fetch_add(local_depth, std::memory_order_relaxed);
     });
     c.drawn = false;
+    if (trace)
+        std::fprintf(stderr, "[mzmcts] moves_collect M=%d: wait for kernels %.1f us, download %.1f us, reconcile %.1f us\n", M,
+                     t_kernels - t_begin, t_copied - t_kernels, now() - t_copied);
     eng->prof.simulations += played_total.load() * eng->p.S;
     eng->prof.select_depth_sum += depth_total.load();
     return MZMCTS_OK;

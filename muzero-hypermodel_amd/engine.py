@@ -67,6 +67,8 @@ class BatchedMCTS:
         self._group_width = int(group_width)
         self.stream = None          # optional dedicated torch.cuda.Stream (PipelinedSearch)
         self._fc_model = None
+        self._ring_moves = ctypes.c_int32()
+        self._batch_keep = []
         self._fc_flat = None
         self.fused_hidden_in_lds = True
 
@@ -420,6 +422,7 @@ class BatchedMCTS:
         self._check(self._lib.mzmcts_moves_prepare(self._h, int(n_moves), self._p_legal, self._p_nlegal, self._p_to_play,
                                                    1 if add_exploration_noise else 0, ptr(t, c_f64_p), self._stream()))
         self._batch_keep = []
+        self._moves_ring()
 
     def moves_predraw_next(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True,
                            num_legal=None):
@@ -452,17 +455,48 @@ class BatchedMCTS:
             raise RuntimeError("no such move in the prepared batch")
         return _device_view(addr, self.E, torch.int32, self.device)
 
-    def moves_collect(self):
+    def _moves_ring(self):
+        """numpy byte view of the library's pinned download ring (built once per ring allocation)."""
+        base, stride = ctypes.c_void_p(), ctypes.c_int64()
+        offsets = (ctypes.c_int64 * 8)()
+        self._check(self._lib.mzmcts_moves_ring(self._h, ctypes.byref(base), ctypes.byref(stride), offsets,
+                                                ctypes.byref(self._ring_moves)))
+        key = (base.value, stride.value, self._ring_moves.value)
+        if getattr(self, "_ring_key", None) != key:
+            nbytes = stride.value * self._ring_moves.value
+            self._ring_raw = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(base.value), dtype=np.uint8)
+            self._ring_key = key
+        return self._ring_raw, stride.value, list(offsets)
+
+    def moves_collect(self, copy=True):
         """Wait for the queued searches.  Returns dict(moves_done [E], actions [M,E], visits [M,E,A],
-        root_value_sum [M,E], root_predicted [M,E], max_depth [M,E]); M = searches queued."""
+        root_value_sum [M,E], root_predicted [M,E], max_depth [M,E]); M = searches queued.
+        copy=False: the per-move arrays are views of the library's pinned download ring (no unpacking pass):
+        valid until the next moves_collect, and an env's entries in moves >= moves_done[e] are undefined."""
         M = len(self._batch_keep)
-        out = dict(moves_done=np.zeros(self.E, np.int32), actions=np.zeros((M, self.E), np.int32),
-                   visits=np.zeros((M, self.E, self.A), np.int32), root_value_sum=np.zeros((M, self.E)),
-                   root_predicted=np.zeros((M, self.E), np.float32), max_depth=np.zeros((M, self.E), np.int32))
-        self._check(self._lib.mzmcts_moves_collect(
-            self._h, ptr(out["moves_done"], c_i32_p), ptr(out["actions"], c_i32_p), ptr(out["visits"], c_i32_p),
-            ptr(out["root_value_sum"], c_f64_p), ptr(out["root_predicted"], c_f32_p), ptr(out["max_depth"], c_i32_p),
-            self._stream()))
+        out = dict(moves_done=np.zeros(self.E, np.int32))
+        if copy:
+            out.update(actions=np.zeros((M, self.E), np.int32), visits=np.zeros((M, self.E, self.A), np.int32),
+                       root_value_sum=np.zeros((M, self.E)), root_predicted=np.zeros((M, self.E), np.float32),
+                       max_depth=np.zeros((M, self.E), np.int32))
+            self._check(self._lib.mzmcts_moves_collect(
+                self._h, ptr(out["moves_done"], c_i32_p), ptr(out["actions"], c_i32_p), ptr(out["visits"], c_i32_p),
+                ptr(out["root_value_sum"], c_f64_p), ptr(out["root_predicted"], c_f32_p), ptr(out["max_depth"], c_i32_p),
+                self._stream()))
+        else:
+            self._check(self._lib.mzmcts_moves_collect(self._h, ptr(out["moves_done"], c_i32_p), None, None, None, None,
+                                                       None, self._stream()))
+            raw, stride, offsets = self._moves_ring()
+
+            def view(offset, dtype, inner):
+                itemsize = np.dtype(dtype).itemsize
+                return np.lib.stride_tricks.as_strided(
+                    raw[offset:].view(dtype), shape=(M,) + inner,
+                    strides=(stride,) + tuple(itemsize * int(np.prod(inner[i + 1:])) for i in range(len(inner))),
+                    writeable=False)
+            out.update(actions=view(offsets[0], np.int32, (self.E,)), visits=view(offsets[1], np.int32, (self.E, self.A)),
+                       root_value_sum=view(offsets[2], np.float64, (self.E,)),
+                       root_predicted=view(offsets[3], np.float32, (self.E,)), max_depth=view(offsets[4], np.int32, (self.E,)))
         self._batch_keep = []
         return out
 

@@ -76,7 +76,7 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
             for _ in range(batch):
                 engine.moves_enqueue(obs)
             engine.moves_predraw_next(batch, legal, to_play, T, True)
-            out = engine.moves_collect()
+            out = engine.moves_collect(copy=False)        # views of the pinned download ring
             engine.moves_submit_next()
         else:
             out = engine.run_moves([obs] * batch, legal, to_play, T, True)
@@ -84,7 +84,7 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
         assert rounds <= 2 * N + 4
         for e in range(E):
             k = out["moves_done"][e]
-            assert (k >= 1) == bool(legal[e]) and (out["actions"][k:, e] == -1).all()
+            assert (k >= 1) == bool(legal[e]) and (k == len(out["actions"]) or out["actions"][k, e] == -1)
             if np.isinf(T[e]) and legal[e]:
                 assert k == 1
             for m in range(k):
