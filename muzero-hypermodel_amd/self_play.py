@@ -688,7 +688,7 @@ class DeviceSelfPlay:
             obs_in = envs.observe(ring["obs_next"][m])[0]    # reset observations where a game ended
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         eng.moves_predraw_next(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
-        out = eng.moves_collect()
+        out = eng.moves_collect(copy=False)             # views: filed (flush) before the next collect overwrites them
         host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         eng.moves_submit_next()
         self._batch_ready = params
