@@ -101,6 +101,15 @@ PROTOTYPES = {
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
     # include/mzenv.h
+    "mzenv_advance": (ctypes.c_int, [c_void] * 10),
+    "mzhist_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(c_void)]),
+    "mzhist_destroy": (None, [c_void]),
+    "mzhist_last_error": (ctypes.c_char_p, [c_void]),
+    "mzhist_begin": (ctypes.c_int, [c_void, c_f32_p, c_i32_p]),
+    "mzhist_file": (ctypes.c_int, [c_void, c_void, c_i32_p]),
+    "mzhist_finished": (ctypes.c_int, [c_void] + [ctypes.POINTER(c_void)] * 8 + [c_i32_p]),
+    "mzhist_lengths": (c_void, [c_void]),
+    "mzhist_rows": (ctypes.c_int, [c_void] * 8 + [ctypes.c_int32]),
     "mzreplay_create": (ctypes.c_int, [c_void, ctypes.POINTER(c_void)]),
     "mzreplay_destroy": (None, [c_void]),
     "mzreplay_last_error": (ctypes.c_char_p, [c_void]),
@@ -183,6 +192,14 @@ def check(lib, engine, rc):
     if rc == ERR_PLAYERS:
         raise NotImplementedError(msg)
     raise RuntimeError(msg)
+
+
+class MzHistMoves(ctypes.Structure):
+    _fields_ = [("n_moves", ctypes.c_int32), ("num_simulations", ctypes.c_int32), ("moves_done", c_void),
+                ("actions", c_void), ("actions_stride", ctypes.c_int64), ("visits", c_void),
+                ("visits_stride", ctypes.c_int64), ("root_value_sum", c_void), ("root_value_sum_stride", ctypes.c_int64),
+                ("legal", c_void), ("num_legal", c_void), ("rewards", c_void), ("done", c_void), ("obs_after", c_void),
+                ("obs_next", c_void), ("to_play_after", c_void), ("to_play_next", c_void)]
 
 
 class HostRng:

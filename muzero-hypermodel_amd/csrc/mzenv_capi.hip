@@ -140,4 +140,17 @@ int mzenv_observe(mzenv* env, float* obs_out, int32_t* legal_out, int32_t* num_l
     return 0;
 }
 
+int mzenv_advance(mzenv* env, const int32_t* actions, float* reward_out, uint8_t* done_out, float* obs_after_out,
+                  float* obs_next_out, int32_t* legal_out, int32_t* num_legal_out, int32_t* to_play_out, void* stream_) {
+    if (!env || !actions || !reward_out || !done_out || !obs_after_out || !obs_next_out || !legal_out || !num_legal_out ||
+        !to_play_out)
+        return env_fail(env, -1, "mzenv_advance: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MZENV_HIP(env, mz::launch_env_step(env->p, actions, reward_out, done_out, stream));
+    MZENV_HIP(env, mz::launch_env_observe(env->p, obs_after_out, legal_out, num_legal_out, to_play_out, stream));
+    MZENV_HIP(env, mz::launch_env_reset(env->p, done_out, stream));
+    MZENV_HIP(env, mz::launch_env_observe(env->p, obs_next_out, legal_out, num_legal_out, to_play_out, stream));
+    return 0;
+}
+
 }  // extern "C"

@@ -85,6 +85,16 @@ class DeviceEnvs:
         self._check(self._lib.mzenv_step(self._h, src.data_ptr(), reward.data_ptr(), done.data_ptr(), self._stream()))
         return reward, done
 
+    def advance(self, actions, reward, done, obs_after, obs_next):
+        """One self-play move of every env in one call: step, observation after the move (terminal ones
+        included), reset of the finished envs, observation the next search sees.  All arguments are resident
+        tensors (actions int32 [E]; outputs as in step / observe)."""
+        self._keep_step = (actions, reward, done, obs_after, obs_next)
+        self._check(self._lib.mzenv_advance(self._h, actions.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                            obs_after.data_ptr(), obs_next.data_ptr(), self.legal.data_ptr(),
+                                            self.num_legal.data_ptr(), self.to_play.data_ptr(), self._stream()))
+        return obs_next
+
     def observe(self, obs=None):
         """(observations [E,C,H,W] f32, legal [E,A] i32, num_legal [E] i32, to_play [E] i32) device tensors;
         the observations go to the caller's `obs` buffer when given."""

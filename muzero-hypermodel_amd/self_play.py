@@ -538,13 +538,114 @@ class PackedGames:
         """Game i as a reference-shaped GameHistory (Python lists)."""
         n = int(self.length[i])
         gh = GameHistory()
-        gh.observation_history = [o for o in self.observations[i, : n + 1]]
+        gh.observation_history = [o.copy() for o in self.observations[i, : n + 1]]   # (the batch may be a view)
         gh.action_history = self.actions[i, : n + 1].tolist()
         gh.reward_history = self.rewards[i, : n + 1].tolist()
         gh.to_play_history = self.to_play[i, : n + 1].tolist()
         gh.child_visits = self.child_visits[i, :n].tolist()
         gh.root_values = self.root_values[i, :n].tolist()
         return gh
+
+
+class HistoryFiler:
+    """Host-side filing of whole move batches into per-env history rows in native code (include/mzhist.h):
+    what DeviceSelfPlay._file_move does one move at a time in numpy, for M moves at once on the library's
+    worker pool.  Finished games come back as PackedGames whose arrays are views of the library's buffers,
+    valid until the next `file` call."""
+
+    def __init__(self, num_envs, max_moves, observation_shape, num_actions):
+        import ctypes
+        from . import _native
+        self._ct, self._native = ctypes, _native
+        self._lib = _native.load()
+        self.E, self.L, self.A = int(num_envs), int(max_moves), int(num_actions)
+        self.observation_shape = tuple(int(v) for v in observation_shape)
+        self.obs_floats = int(numpy.prod(self.observation_shape))
+        handle = ctypes.c_void_p()
+        if self._lib.mzhist_create(self.E, self.L, self.obs_floats, self.A, ctypes.byref(handle)) != 0:
+            raise RuntimeError("mzhist_create failed")
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mzhist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self, first_observations, first_to_play=None):
+        obs = numpy.ascontiguousarray(first_observations, dtype=numpy.float32).reshape(self.E, self.obs_floats)
+        tp = None if first_to_play is None else numpy.ascontiguousarray(first_to_play, dtype=numpy.int32)
+        self._lib.mzhist_begin(self._h, self._native.ptr(obs, self._native.c_f32_p),
+                               None if tp is None else self._native.ptr(tp, self._native.c_i32_p))
+
+    def load_rows(self, obs, act, rew, tp, cv, rv, lengths):
+        """Take over running games kept as numpy rows ([E, L+1, ...] / [E, L, ...] arrays, lengths [E])."""
+        self._rows(obs, act, rew, tp, cv, rv, lengths, 1)
+
+    def store_rows(self, obs, act, rew, tp, cv, rv, lengths):
+        """Hand the running games back into numpy rows of the same shapes."""
+        self._rows(obs, act, rew, tp, cv, rv, lengths, 0)
+
+    def _rows(self, obs, act, rew, tp, cv, rv, lengths, load):
+        n = self._native
+        assert obs.shape[1] == self.L + 1 and obs.dtype == numpy.float32 and act.dtype == numpy.int32
+        assert rew.dtype == numpy.float32 and cv.dtype == numpy.float64 and rv.dtype == numpy.float64
+        tp32 = numpy.ascontiguousarray(tp, dtype=numpy.int32)
+        len32 = numpy.ascontiguousarray(lengths, dtype=numpy.int32)
+        rc = self._lib.mzhist_rows(self._h, obs.ctypes.data, act.ctypes.data, rew.ctypes.data, tp32.ctypes.data,
+                                   cv.ctypes.data, rv.ctypes.data, len32.ctypes.data, load)
+        if rc != 0:
+            raise RuntimeError("mzhist_rows failed")
+        if not load:
+            tp[...] = tp32
+            lengths[...] = len32
+
+    def lengths(self):
+        addr = self._lib.mzhist_lengths(self._h)
+        return numpy.ctypeslib.as_array(self._ct.cast(addr, self._ct.POINTER(self._ct.c_int32)), shape=(self.E,))
+
+    def file(self, out, legal, num_legal, num_simulations, rewards, done, obs_after, obs_next):
+        """out: engine.moves_collect() result (copies or ring views); rewards f32 [M,E], done u8 [M,E],
+        obs_after / obs_next f32 [M,E,...] host arrays.  Returns PackedGames of the games that ended, or None."""
+        ct = self._ct
+        M = int(out["actions"].shape[0])
+        keep = [numpy.ascontiguousarray(out["moves_done"], dtype=numpy.int32),
+                numpy.ascontiguousarray(legal, dtype=numpy.int32), numpy.ascontiguousarray(num_legal, dtype=numpy.int32),
+                numpy.ascontiguousarray(rewards, dtype=numpy.float32), numpy.ascontiguousarray(done, dtype=numpy.uint8),
+                numpy.ascontiguousarray(obs_after, dtype=numpy.float32), numpy.ascontiguousarray(obs_next, dtype=numpy.float32)]
+        mv = self._native.MzHistMoves()
+        mv.n_moves, mv.num_simulations = M, int(num_simulations)
+        mv.moves_done = keep[0].ctypes.data
+        for name, key in (("actions", "actions"), ("visits", "visits"), ("root_value_sum", "root_value_sum")):
+            a = out[key]
+            setattr(mv, name, a.ctypes.data)
+            setattr(mv, name + "_stride", int(a.strides[0]) if M else 0)
+        mv.legal, mv.num_legal = keep[1].ctypes.data, keep[2].ctypes.data
+        mv.rewards, mv.done, mv.obs_after, mv.obs_next = (k.ctypes.data for k in keep[3:7])
+        mv.to_play_after = mv.to_play_next = None
+        n = ct.c_int32()
+        if self._lib.mzhist_file(self._h, ct.byref(mv), ct.byref(n)) != 0:
+            raise RuntimeError(self._lib.mzhist_last_error(self._h).decode())
+        if n.value == 0:
+            return None
+        ptrs = [ct.c_void_p() for _ in range(8)]
+        row = ct.c_int32()
+        count = self._lib.mzhist_finished(self._h, *[ct.byref(p) for p in ptrs], ct.byref(row))
+        W = row.value
+
+        def arr(p, ctype, shape):
+            return numpy.ctypeslib.as_array(ct.cast(p, ct.POINTER(ctype)), shape=shape)
+        return PackedGames(env_index=arr(ptrs[0], ct.c_int32, (count,)), length=arr(ptrs[1], ct.c_int32, (count,)),
+                           observations=arr(ptrs[2], ct.c_float, (count, W + 1) + self.observation_shape),
+                           actions=arr(ptrs[3], ct.c_int32, (count, W + 1)), rewards=arr(ptrs[4], ct.c_float, (count, W + 1)),
+                           to_play=arr(ptrs[5], ct.c_int32, (count, W + 1)),
+                           child_visits=arr(ptrs[6], ct.c_double, (count, W, self.A)),
+                           root_values=arr(ptrs[7], ct.c_double, (count, W)))
 
 
 class DeviceSelfPlay:
@@ -609,6 +710,9 @@ class DeviceSelfPlay:
         """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
         self._drop_batch()
         self.flush(on_game, on_games)
+        if getattr(self, "_filer_owns_rows", False):
+            self._filer.store_rows(self._obs, self._act, self._rew, self._tp, self._cv, self._rv, self._len)
+            self._filer_owns_rows = False
         cur = self._cur
         self.engine.search(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True, num_legal=cur["num_legal"])
         if temperature_threshold:
@@ -682,36 +786,49 @@ class DeviceSelfPlay:
         obs_in = cur["obs_dev"]
         for m in range(n_moves):
             eng.moves_enqueue(obs_in.reshape(E, -1))
-            envs.step(eng.moves_actions(m), ring["reward"][m], ring["done"][m])
-            envs.observe(ring["obs_after"][m])               # terminal observations included
-            envs.reset(ring["done"][m])
-            obs_in = envs.observe(ring["obs_next"][m])[0]    # reset observations where a game ended
+            # step, terminal observation, reset of the finished envs, next observation: one call, four launches
+            obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
+                                  ring["obs_next"][m])
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         eng.moves_predraw_next(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
-        out = eng.moves_collect(copy=False)             # views: filed (flush) before the next collect overwrites them
+        out = eng.moves_collect(copy=False)                  # views: filed (flush) before the next collect overwrites them
         host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         eng.moves_submit_next()
         self._batch_ready = params
-        self._unfiled = (out, host, cur["legal"], cur["to_play"], n_moves)
+        self._unfiled = (out, host, cur["legal"], cur["num_legal"], n_moves)
         self._cur = dict(cur, obs_dev=obs_in, obs=host["obs_next"][n_moves - 1])
         self.moves_played += int(out["moves_done"].sum())
-        return out["moves_done"]
+        return out["moves_done"].copy()
 
     def flush(self, on_game=None, on_games=None):
         """File the moves of the last play_moves batch into the histories (play_moves does this for the
-        batch before while the GPU runs the current one; call it once at the end)."""
+        batch before while the GPU runs the current one; call it once at the end).  Native code
+        (HistoryFiler, include/mzhist.h): one pass over the batch on the library's worker pool."""
         if getattr(self, "_unfiled", None) is None:
             return
-        out, host, legal, to_play, n_moves = self._unfiled
+        out, host, legal, num_legal, n_moves = self._unfiled
         self._unfiled = None
-        S = float(self.config.num_simulations)
-        done = host["done"].astype(bool)
-        for m in range(n_moves):
-            child_visits = numpy.zeros((self.E, self.envs.A))
-            numpy.put_along_axis(child_visits, legal.astype(numpy.int64), out["visits"][m] / S, axis=1)
-            self._file_move(out["moves_done"] > m, out["actions"][m], child_visits, out["root_value_sum"][m] / S,
-                            host["reward"][m], done[m], host["obs_after"][m], to_play, host["obs_next"][m], to_play,
-                            on_game, on_games)
+        filer = self._history_filer()
+        batch = filer.file(out, legal, num_legal, self.config.num_simulations, host["reward"], host["done"],
+                           host["obs_after"], host["obs_next"])
+        self._len[:] = filer.lengths()
+        if batch is not None:
+            self.games_finished += len(batch)
+            if on_games is not None:
+                on_games(batch)
+            if on_game is not None:
+                for i, e in enumerate(batch.env_index):
+                    on_game(int(e), batch.history(i))
+
+    def _history_filer(self):
+        """The native filer takes over the rows of the running games (and hands them back to step())."""
+        filer = getattr(self, "_filer", None)
+        if filer is None:
+            filer = self._filer = HistoryFiler(self.E, int(self.config.max_moves) + 1, self.envs.observation_shape, self.envs.A)
+        if not getattr(self, "_filer_owns_rows", False):
+            filer.load_rows(self._obs, self._act, self._rew, self._tp, self._cv, self._rv, self._len)
+            self._filer_owns_rows = True
+        return filer
 
     def _drop_batch(self):
         """Forget the batch that was drawn and uploaded ahead (its noise goes back into the RNG streams)."""

@@ -48,7 +48,8 @@ def main():
         cb = dict(on_game=on_game) if kind in ("host", "device-lists") else dict(on_games=on_games)
         if kind == "device-batch":
             # searches, env steps and resets queued back to back, `--batch` moves per host round trip
-            actor.play_moves(args.batch, 1.0, **cb)
+            for _ in range(3):                       # buffers, the native history filer, the pre-drawn next batch
+                actor.play_moves(args.batch, 1.0, **cb)
             torch.cuda.synchronize()
             done[0] = 0
             t0 = time.perf_counter()
