@@ -65,7 +65,8 @@ def main():
         recent = finished[-50:]
         row = dict(iteration=it, training_step=trainer.training_step, played_steps=int(actor.moves_played),
                    games=len(finished), mean_reward_last_50=float(np.mean(recent)) if recent else None,
-                   max_reward=float(np.max(finished)) if finished else None, temperature=temperature,
+                   max_reward=float(np.max(finished)) if finished else None,
+                   mean_length_of_running_games=float(np.mean(actor._len)), temperature=temperature,
                    total_loss=losses[0] if losses else None, seconds=time.perf_counter() - t0)
         log.append(row)
         print(json.dumps(row), flush=True)
