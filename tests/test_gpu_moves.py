@@ -137,3 +137,34 @@ def test_move_batch_actions_are_on_the_device(eng, pkg):
     with pytest.raises(RuntimeError, match="temperature 0, inf or 1/k"):
         engine.moves_prepare(2, [[0, 1]] * E, [0] * E, 0.3)
     engine.close()
+
+
+def test_move_batches_without_exploration_noise(eng, pkg):
+    """add_exploration_noise=False (the reference's test mode): no Dirichlet rows, the streams only advance by
+    the tie-break and sampling words -- batches still equal the one-move-at-a-time path."""
+    config, model = cartpole_setup(pkg, False)
+    E, N = 40, 9
+    obs = torch.from_numpy(np.random.RandomState(8).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()
+    legal, to_play, T = [[0, 1]] * E, [0] * E, np.where(np.arange(E) % 2, 1.0, 0.0)
+    seeds = [77 + e for e in range(E)]
+    ref = eng.BatchedMCTS(config, E, seeds=seeds, group_width=16)
+    ref.configure_fused_fc(model)
+    want = []
+    for _ in range(N):
+        st = ref.search_fused(obs, legal, to_play, False)
+        actions, _ = ref.sample_actions(T)
+        want.append((actions.copy(), st["visits"].copy(), st["root_value_sum"].copy()))
+    ref.close()
+    engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=16)
+    engine.configure_fused_fc(model)
+    got = [[] for _ in range(E)]
+    while min(len(g) for g in got) < N:
+        out = engine.run_moves([obs] * 3, legal, to_play, T, False)
+        for e in range(E):
+            for m in range(out["moves_done"][e]):
+                got[e].append((out["actions"][m, e], out["visits"][m, e].copy(), out["root_value_sum"][m, e]))
+    engine.close()
+    for e in range(E):
+        for i in range(N):
+            assert got[e][i][0] == want[i][0][e] and np.array_equal(got[e][i][1], want[i][1][e]), (e, i)
+            assert got[e][i][2] == want[i][2][e]
