@@ -109,3 +109,21 @@ def test_host_select_action_g8(native, golden):
             r = native.HostRng(100 + i)
             picks = [int(actions[r.select_action(visits, T)]) for _ in range(12)]
             assert picks == fx[f"set{i}_T{T}"].tolist(), (i, T)
+
+
+def test_host_rng_replay_sampling_helpers_match_numpy(native):
+    """choice_p_many == RandomState.choice(n, size, p=p); choice_priorities == the reference's sample_position
+    arithmetic (float32 priorities / Python sum of float32 scalars, replay_buffer.py:178-181)."""
+    import numpy as np
+    rs = np.random.RandomState(5)
+    p32 = rs.rand(37).astype(np.float32)
+    p32 /= np.sum(p32)
+    got = native.HostRng(123).choice_p_many(p32, 50)
+    want = np.random.RandomState(123).choice(37, 50, p=p32)
+    assert np.array_equal(got, want)
+    priorities = (rs.rand(23) * 3).astype(np.float32)
+    probs = priorities / sum(priorities)
+    for seed in (1, 2, 3):
+        idx, prob = native.HostRng(seed).choice_priorities(priorities)
+        want_idx = np.random.RandomState(seed).choice(len(probs), p=probs)
+        assert idx == want_idx and prob == probs[want_idx]
