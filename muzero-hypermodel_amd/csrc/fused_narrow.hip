@@ -194,8 +194,12 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
 
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
     for (int sim = 0; sim < n_sims; ++sim) {
-        const Descent d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j,
-                                                  group_base, p.error_flag MZ_DSTAMP_ARGS);
+        Descent d;
+        if constexpr (SPAN == 2)
+            d = descend_pair<PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, p.error_flag);
+        else
+            d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, group_base,
+                                        p.error_flag MZ_DSTAMP_ARGS);
         MZ_STAMP(2);
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
         const float state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];

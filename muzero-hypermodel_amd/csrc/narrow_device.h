@@ -382,6 +382,92 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
     return Descent{depth, k, slot};
 }
 
+// The same loop for A <= 2, software-pipelined.  Every even lane of the row plays child 0 and every odd lane
+// child 1 (eight redundant pairs: decisions are uniform over the row without any broadcast).  At the top of a
+// level a lane already holds its child's record; it immediately issues the loads of BOTH records of the block
+// that child points to -- X = the record this lane would keep if its own child is selected, Y = the record its
+// partner would need -- so the LDS round trip of the next level runs under this level's score / arg-max work
+// instead of after it.  After the selection the lane keeps X or takes its partner's Y (quad-perm DPP).
+struct ChildRecord {
+    double prior, vterm;
+    int visits, child;
+};
+
+__device__ __forceinline__ ChildRecord load_record(const LdsTreeV& acc, int k, int c) {
+    const ChildStats* st = acc.stats(k) + c;
+    const ChildLinks* lk = acc.links(k) + c;
+    return ChildRecord{st->prior, acc.vterm(k)[c], lk->visits, lk->child_node};
+}
+
+__device__ __forceinline__ ChildRecord swap_record(const ChildRecord& r) {
+    return ChildRecord{partner<1>(r.prior), partner<1>(r.vterm), partner_bits<1>(r.visits), partner_bits<1>(r.child)};
+}
+
+template <bool PBC2>
+__device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
+                                                int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
+                                                int32_t& mt_pos, uint32_t& words, int j, int32_t* error_flag) {
+    const bool has_range = mm.maximum > mm.minimum;
+    const double range = mm.maximum - mm.minimum;
+    const int c = j & 1;
+    int n_children = n_root_children;
+    int k = 0, N = sim, depth = 0, slot = 0;
+    ChildRecord rec = load_record(acc, 0, c < n_children ? c : 0);
+    for (;;) {
+        const bool valid = c < n_children;
+        // next level's records, both candidates: in flight while this level is scored
+        const int ck = rec.child >= 0 ? rec.child : 0;
+        const bool next_pair = A > 1;
+        const ChildRecord X = load_record(acc, ck, next_pair ? c : 0);
+        const ChildRecord Y = load_record(acc, ck, next_pair ? 1 - c : 0);
+        double pb;
+        if constexpr (PBC2) {
+            pb = pbc2[(__mul24(N, N + 1) >> 1) + rec.visits];
+        } else {
+            pb = pbc[N];
+            pb = pb * (pbc[S + 1 + N] / static_cast<double>(rec.visits + 1));
+        }
+        const double prior_score = pb * rec.prior;
+        double normalized = (rec.vterm - mm.minimum) / range;  // discarded unless visited and max > min
+        asm volatile("" : "+v"(normalized));
+        const double value_score = rec.visits > 0 ? (has_range ? normalized : rec.vterm) : 0.0;
+        const double score = valid ? prior_score + value_score : -INFINITY;
+        const double other = partner<1>(score);
+        // select_child (self_play.py:364-379) over two children
+        const bool wins = score > other, loses = other > score;
+        bool mine = wins;
+        if (!(wins || loses)) {          // (the same for every lane of the row)
+            if (score == other) {        // tie: numpy.random.choice over [0, 1]
+                int r = 0;
+                if (j == 0) r = static_cast<int>(mt_below(mt_key, &mt_pos, 2u, &words));
+                r = row_or(r);
+                mine = r == c;
+            } else {                     // NaN scores: the reference would raise; flag and take slot 0
+                if (j == 0) atomicOr(error_flag, 1);
+                mine = c == 0;
+            }
+        }
+        slot = mine ? c : 1 - c;
+        // (the DPP reads stay outside the conditionals: a lane that is masked off hands its partner a zero)
+        const int partner_child = partner_bits<1>(rec.child), partner_visits = partner_bits<1>(rec.visits);
+        const int sel_child = mine ? rec.child : partner_child;
+        const int sel_visits = mine ? rec.visits : partner_visits;
+        if (j == 0) acc.path_store(depth, (k << 16) | slot);
+        ++depth;
+        if (sel_child < 0) break;
+        if (depth > sim) {  // cannot happen on a consistent tree; guarantees every wave leaves the loop
+            if (j == 0) atomicOr(error_flag, 2);
+            break;
+        }
+        const ChildRecord from_partner = swap_record(Y);
+        rec = mine ? X : from_partner;
+        k = sel_child;
+        N = sel_visits;
+        n_children = A;
+    }
+    return Descent{depth, k, slot};
+}
+
 // backpropagate (self_play.py:407-431) for a tree in LDS, lane = path level (16 levels per round, leaf
 // side first).  Every lane fetches its node; the value recursion `value = (+-r) + discount * value` runs
 // down the lanes through row_shl:1 (each step recomputes all lanes; a lane is final one step after its
