@@ -415,11 +415,7 @@ __device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const doubl
     ChildRecord rec = load_record(acc, 0, c < n_children ? c : 0);
     for (;;) {
         const bool valid = c < n_children;
-        // next level's records, both candidates: in flight while this level is scored
-        const int ck = rec.child >= 0 ? rec.child : 0;
-        const bool next_pair = A > 1;
-        const ChildRecord X = load_record(acc, ck, next_pair ? c : 0);
-        const ChildRecord Y = load_record(acc, ck, next_pair ? 1 - c : 0);
+        // this level's exploration factor first (LDS answers in order: what is needed first is asked first) ...
         double pb;
         if constexpr (PBC2) {
             pb = pbc2[(__mul24(N, N + 1) >> 1) + rec.visits];
@@ -427,6 +423,11 @@ __device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const doubl
             pb = pbc[N];
             pb = pb * (pbc[S + 1 + N] / static_cast<double>(rec.visits + 1));
         }
+        // ... then the next level's records, both candidates: in flight while this level is scored
+        const int ck = rec.child >= 0 ? rec.child : 0;
+        const bool next_pair = A > 1;
+        const ChildRecord X = load_record(acc, ck, next_pair ? c : 0);
+        const ChildRecord Y = load_record(acc, ck, next_pair ? 1 - c : 0);
         const double prior_score = pb * rec.prior;
         double normalized = (rec.vterm - mm.minimum) / range;  // discarded unless visited and max > min
         asm volatile("" : "+v"(normalized));
