@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     uint32_t* mt_key = p.mt_key + static_cast<size_t>(e) * kMtN;
     MZ_STAMP(1);
 
+    const ResidentWeights resident = load_resident_weights(units, bias, j);
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
     for (int sim = 0; sim < n_sims; ++sim) {
         Descent d;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
         const float state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
         const float x0 = (j < enc) ? state : ((j - enc == action) ? 1.f : 0.f);
-        const NarrowHeads h = narrow_recurrent(units, bias, enc, wide_support, x0, j);
+        const NarrowHeads h = narrow_recurrent(units, bias, enc, wide_support, x0, j, resident);
         MZ_STAMP(3);
         float value_f, reward_f;
         narrow_support_pair(h.value_a, h.value_b, h.reward_a, h.reward_b, net.F, net.support, j, value_f, reward_f);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) void fc_inference_narrow_kernel(
         const int a = static_cast<int>(action[e]);
         const float state = in[static_cast<size_t>(e) * net.enc + (j < net.enc ? j : 0)];
         const float x0 = (j < net.enc) ? state : ((j - net.enc == a) ? 1.f : 0.f);
-        h = narrow_recurrent(units, bias, net.enc, wide_support, x0, j);
+        h = narrow_recurrent(units, bias, net.enc, wide_support, x0, j, load_resident_weights(units, bias, j));
     }
     if (j < net.enc) hidden_out[static_cast<size_t>(e) * net.enc + j] = h.norm;
     if (j < net.A) policy_logits[static_cast<size_t>(e) * net.A + j] = h.policy;

@@ -148,11 +148,20 @@ __device__ __forceinline__ void stage_narrow_units(const FcNet& net, const float
 // will not fold a DPP move into the tied-accumulator form (it emits mov_dpp + fmac + hazard nops: 2.4x the
 // issue slots).  Two accumulators halve the dependent chain.  Hazards the assembler cannot see inside the
 // block: a VALU write of x (or of EXEC) immediately before the first DPP read -- covered by the leading nop.
+struct UnitWeights {
+    float4 w0, w1, w2, w3;
+    float bias;
+};
+
+// the 16 weights (rotation order) and the bias of this lane's neuron of unit U: four 16-byte LDS reads
 template <int U>
-__device__ __forceinline__ float narrow_unit(const float4* units, const float* bias, float x, int j) {
+__device__ __forceinline__ UnitWeights load_unit(const float4* units, const float* bias, int j) {
     const float4* w = units + (U * 4) * kRow + j;
-    const float4 w0 = w[0], w1 = w[kRow], w2 = w[2 * kRow], w3 = w[3 * kRow];
-    float a = bias[U * kRow + j];
+    return UnitWeights{w[0], w[kRow], w[2 * kRow], w[3 * kRow], bias[U * kRow + j]};
+}
+
+__device__ __forceinline__ float apply_unit(const UnitWeights& u, float x) {
+    float a = u.bias;
     float b = 0.f;
     asm volatile(
         "s_nop 4\n\t"
@@ -173,9 +182,19 @@ __device__ __forceinline__ float narrow_unit(const float4* units, const float* b
         "v_fmac_f32_dpp %0, %2, %17 row_ror:14 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %1, %2, %18 row_ror:15 row_mask:0xf bank_mask:0xf"
         : "+v"(a), "+v"(b)
-        : "v"(x), "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x),
-          "v"(w2.y), "v"(w2.z), "v"(w2.w), "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w));
+        : "v"(x), "v"(u.w0.x), "v"(u.w0.y), "v"(u.w0.z), "v"(u.w0.w), "v"(u.w1.x), "v"(u.w1.y), "v"(u.w1.z), "v"(u.w1.w),
+          "v"(u.w2.x), "v"(u.w2.y), "v"(u.w2.z), "v"(u.w2.w), "v"(u.w3.x), "v"(u.w3.y), "v"(u.w3.z), "v"(u.w3.w));
     return a + b;
+}
+
+// bias + W x for this lane's neuron of unit U; x holds the layer input, element k in lane k (0 beyond it).
+// Sixteen v_fmac_f32 whose activation operand carries the DPP row rotate, written out because the compiler
+// will not fold a DPP move into the tied-accumulator form (it emits mov_dpp + fmac + hazard nops: 2.4x the
+// issue slots).  Two accumulators halve the dependent chain.  Hazards the assembler cannot see inside the
+// block: a VALU write of x (or of EXEC) immediately before the first DPP read -- covered by the leading nop.
+template <int U>
+__device__ __forceinline__ float narrow_unit(const float4* units, const float* bias, float x, int j) {
+    return apply_unit(load_unit<U>(units, bias, j), x);
 }
 
 __device__ __forceinline__ float narrow_elu(float v) { return v > 0.f ? v : elu_negative(v); }
@@ -197,19 +216,37 @@ struct NarrowHeads {
 };
 
 // models.py:147-170, 192-195 recurrent_inference; x0 = [hidden | one-hot(action)] across the lanes
+// the weights a lane needs for the first phases of every recurrent inference: kept in registers across the
+// simulations of a move (the kernel runs one wave per SIMD: the register file is otherwise idle)
+struct ResidentWeights {
+    UnitWeights dyn1, dyn2, rew1, val1, pol1;
+};
+
+__device__ __forceinline__ ResidentWeights load_resident_weights(const float4* units, const float* bias, int j) {
+    return ResidentWeights{load_unit<kUDyn1>(units, bias, j), load_unit<kUDyn2>(units, bias, j),
+                           load_unit<kURew1>(units, bias, j), load_unit<kUVal1>(units, bias, j),
+                           load_unit<kUPol1>(units, bias, j)};
+}
+
+// the remaining weights are asked for a phase ahead of their use, so that their LDS round trips run under the
+// previous phase's arithmetic (the addresses never change; only the activations are on the dependent chain)
 __device__ __forceinline__ NarrowHeads narrow_recurrent(const float4* units, const float* bias, int enc, bool wide_support,
-                                                        float x0, int j) {
+                                                        float x0, int j, const ResidentWeights& resident) {
     NarrowHeads h{};
-    const float d1 = narrow_elu(narrow_unit<kUDyn1>(units, bias, x0, j));
-    const float raw = narrow_unit<kUDyn2>(units, bias, d1, j);
+    const UnitWeights &wd1 = resident.dyn1, &wd2 = resident.dyn2, &wr1 = resident.rew1, &wv1 = resident.val1,
+                      &wp1 = resident.pol1;
+    const float d1 = narrow_elu(apply_unit(wd1, x0));
+    const float raw = apply_unit(wd2, d1);
+    const UnitWeights wr2 = load_unit<kURew2a>(units, bias, j), wv2 = load_unit<kUVal2a>(units, bias, j),
+                      wp2 = load_unit<kUPol2>(units, bias, j);
     h.norm = narrow_rescale(raw, enc, j);
     // the reward head reads the UN-normalised next state (models.py:157-159)
-    const float r1 = narrow_elu(narrow_unit<kURew1>(units, bias, raw, j));
-    const float v1 = narrow_elu(narrow_unit<kUVal1>(units, bias, h.norm, j));
-    const float p1 = narrow_elu(narrow_unit<kUPol1>(units, bias, h.norm, j));
-    h.reward_a = narrow_unit<kURew2a>(units, bias, r1, j);
-    h.value_a = narrow_unit<kUVal2a>(units, bias, v1, j);
-    h.policy = narrow_unit<kUPol2>(units, bias, p1, j);
+    const float r1 = narrow_elu(apply_unit(wr1, raw));
+    const float v1 = narrow_elu(apply_unit(wv1, h.norm));
+    const float p1 = narrow_elu(apply_unit(wp1, h.norm));
+    h.reward_a = apply_unit(wr2, r1);
+    h.value_a = apply_unit(wv2, v1);
+    h.policy = apply_unit(wp2, p1);
     h.reward_b = 0.f;
     h.value_b = 0.f;
     if (wide_support) {
