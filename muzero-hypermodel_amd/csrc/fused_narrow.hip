@@ -196,14 +196,17 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
     for (int sim = 0; sim < n_sims; ++sim) {
         Descent d;
-        if constexpr (SPAN == 2)
-            d = descend_pair<PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, p.error_flag);
-        else
+        float state;
+        if constexpr (SPAN == 2) {
+            d = descend_pair<PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, p.error_flag,
+                                   hidden_lds, enc, state);
+        } else {
             d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, group_base,
                                         p.error_flag MZ_DSTAMP_ARGS);
+            state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
+        }
         MZ_STAMP(2);
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
-        const float state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
         const float x0 = (j < enc) ? state : ((j - enc == action) ? 1.f : 0.f);
         const NarrowHeads h = narrow_recurrent(units, bias, enc, wide_support, x0, j, resident);
         MZ_STAMP(3);

@@ -456,10 +456,15 @@ __device__ __forceinline__ ChildRecord swap_record(const ChildRecord& r) {
 template <bool PBC2>
 __device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
                                                 int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
-                                                int32_t& mt_pos, uint32_t& words, int j, int32_t* error_flag) {
+                                                int32_t& mt_pos, uint32_t& words, int j, int32_t* error_flag,
+                                                const float* hidden_lds, int enc, float& parent_state) {
+    // parent_state: element j of the hidden state of the node the descent ends under -- asked for at the top
+    // of every level (the current node is the leaf's parent if this level is the last), so that the network's
+    // input is in a register when the loop ends instead of one LDS round trip later
     const bool has_range = mm.maximum > mm.minimum;
     const double range = mm.maximum - mm.minimum;
     const int c = j & 1;
+    const int hidden_lane = j < enc ? j : 0;
     int n_children = n_root_children;
     int k = 0, N = sim, depth = 0, slot = 0;
     ChildRecord rec = load_record(acc, 0, c < n_children ? c : 0);
@@ -473,6 +478,7 @@ __device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const doubl
             pb = pbc[N];
             pb = pb * (pbc[S + 1 + N] / static_cast<double>(rec.visits + 1));
         }
+        parent_state = hidden_lds[__mul24(k, enc) + hidden_lane];
         // ... then the next level's records, both candidates: in flight while this level is scored
         const int ck = rec.child >= 0 ? rec.child : 0;
         const bool next_pair = A > 1;
