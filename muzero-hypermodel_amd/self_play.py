@@ -792,7 +792,14 @@ class DeviceSelfPlay:
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         eng.moves_predraw_next(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
         out = eng.moves_collect(copy=False)                  # views: filed (flush) before the next collect overwrites them
-        host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
+        # env outputs of the batch: one asynchronous copy each into pinned host buffers (alternating sets, so that
+        # the batch waiting to be filed keeps its own), one wait
+        pinned = ring["pinned"][ring["flip"]]
+        ring["flip"] ^= 1
+        for k in ("reward", "done", "obs_after", "obs_next"):
+            pinned[k][:n_moves].copy_(ring[k][:n_moves], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = {k: pinned[k][:n_moves].numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         eng.moves_submit_next()
         self._batch_ready = params
         self._unfiled = (out, host, cur["legal"], cur["num_legal"], n_moves)
@@ -844,6 +851,9 @@ class DeviceSelfPlay:
                         done=torch.zeros((n_moves, self.E), dtype=torch.uint8, device=dev),
                         obs_after=torch.zeros((n_moves, self.E) + shape, dtype=torch.float32, device=dev),
                         obs_next=torch.zeros((n_moves, self.E) + shape, dtype=torch.float32, device=dev))
+            ring["pinned"] = [{k: torch.zeros(ring[k].shape, dtype=ring[k].dtype).pin_memory()
+                               for k in ("reward", "done", "obs_after", "obs_next")} for _ in range(2)]
+            ring["flip"] = 0
             self._ring = ring
         return ring
 
