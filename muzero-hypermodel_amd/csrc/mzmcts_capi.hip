@@ -89,7 +89,7 @@ class WorkerPool {
     ~WorkerPool() {
         {
             std::lock_guard<std::mutex> lock(mu_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_release);
             generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
@@ -105,10 +105,11 @@ class WorkerPool {
         int chunk = n / ((size() + 1) * per_thread);
         if (chunk < 16) chunk = 16;
         const uint64_t g = generation_.load(std::memory_order_relaxed) + 1;
-        body_ = &body;
-        n_ = n;
-        chunk_ = chunk;
-        total_ = (n + chunk - 1) / chunk;
+        const uint32_t total = static_cast<uint32_t>((n + chunk - 1) / chunk);
+        body_.store(&body, std::memory_order_relaxed);
+        n_.store(n, std::memory_order_relaxed);
+        chunk_.store(chunk, std::memory_order_relaxed);
+        total_.store(total, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
         next_.store(g << 32, std::memory_order_release);  // publishes the fields above for generation g
         {
@@ -117,21 +118,27 @@ class WorkerPool {
         }
         cv_.notify_all();
         work(g);
-        while (done_.load(std::memory_order_acquire) < total_) __builtin_ia32_pause();
-        body_ = nullptr;
+        while (done_.load(std::memory_order_acquire) < total) __builtin_ia32_pause();
+        // Close the job: a worker that read the claim word before this point and was descheduled must fail its
+        // compare-exchange instead of claiming a chunk of whatever job comes next.
+        next_.store((g << 32) | kClosed, std::memory_order_release);
+        body_.store(nullptr, std::memory_order_relaxed);
     }
 
   private:
+    static constexpr uint32_t kClosed = 0xffffffffu;
     // claim chunks of generation g until none is left (or the job has moved on)
     void work(uint64_t g) {
         for (;;) {
             uint64_t cur = next_.load(std::memory_order_acquire);
             if ((cur >> 32) != g) return;
-            const int idx = static_cast<int>(cur & 0xffffffffu);
-            if (idx >= total_) return;  // (fields belong to generation g: they were written before next_ carried g)
+            const uint32_t idx = static_cast<uint32_t>(cur & 0xffffffffu);
+            if (idx >= total_.load(std::memory_order_relaxed)) return;
+            // a successful exchange proves the claim word still belongs to generation g, hence so do the fields
             if (!next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
-            const int lo = idx * chunk_, hi = std::min(n_, lo + chunk_);
-            (*body_)(lo, hi);  // the job cannot complete (and the fields cannot change) before this chunk is counted
+            const int chunk = chunk_.load(std::memory_order_relaxed);
+            const int lo = static_cast<int>(idx) * chunk, hi = std::min(n_.load(std::memory_order_relaxed), lo + chunk);
+            (*body_.load(std::memory_order_relaxed))(lo, hi);  // the job cannot complete before this chunk is counted
             done_.fetch_add(1, std::memory_order_release);
         }
     }
@@ -152,19 +159,19 @@ class WorkerPool {
                 cv_.wait(lock, [&] { return generation_.load(std::memory_order_acquire) != seen; });
             }
             seen = generation_.load(std::memory_order_acquire);
-            if (stop_) return;
+            if (stop_.load(std::memory_order_acquire)) return;
             work(seen);
         }
     }
     std::vector<std::thread> threads_;
     std::mutex mu_, run_mu_;
     std::condition_variable cv_;
-    const std::function<void(int, int)>* body_ = nullptr;
-    int n_ = 0, chunk_ = 0, total_ = 0;
-    std::atomic<int> done_{0};
+    std::atomic<const std::function<void(int, int)>*> body_{nullptr};
+    std::atomic<int> n_{0}, chunk_{0};
+    std::atomic<uint32_t> total_{0}, done_{0};
     std::atomic<uint64_t> next_{0};
     std::atomic<uint64_t> generation_{0};
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
 };
 
 int host_worker_count(int n_items) {
@@ -544,6 +551,7 @@ void mzmcts_destroy(mzmcts_engine* eng) {
         (void)hipEventDestroy(ev.end);
     }
     if (eng->readout_event) (void)hipEventDestroy(eng->readout_event);
+    if (eng->batch.done) (void)hipEventDestroy(eng->batch.done);
     for (void* ptr : eng->device_allocs) (void)hipFree(ptr);
     for (void* ptr : eng->pinned_allocs) (void)hipHostFree(ptr);
     delete eng;
