@@ -6,7 +6,6 @@ import socket
 import sys
 
 import numpy
-import pytest
 import torch
 import torch.multiprocessing as mp
 

@@ -4,11 +4,9 @@ actions / gradient scales / stacked observations / importance weights bit for bi
 import importlib
 import os
 import sys
-import types
 
 import numpy as np
 import pytest
-import torch
 
 from parity_helpers import load_golden
 from test_oracle_replay import NAMES, cfg_of, games_of

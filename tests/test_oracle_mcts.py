@@ -167,7 +167,6 @@ def test_oracle_native_fc_run_matches_reference_targets(oracle, golden):
     expectation x is amplified ~100x.  So value targets are held to 3e-5 relative wherever both
     runs walked identical paths; policy targets (visit ratios) are then exactly equal.
     """
-    import ctypes
     fx = golden("g4_cartpole_traces")
     w = golden("cartpole_weights")
     net = oracle.FcNet({k: w[k] for k in w.files}, 4, 8, 2, 10, [], [16], [16], [16], [16])

@@ -15,7 +15,6 @@ e.configure_fused_fc(model)
 obs = torch.from_numpy(np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()
 legal = np.tile(np.arange(2, dtype=np.int32), (E, 1)); nl = np.full(E, 2, np.int32); tp = np.zeros(E, np.int32)
 temp = np.ones(E)
-import ctypes
 t = dict(begin=0.0, launch=0.0, readout=0.0, sample=0.0, stats=0.0)
 N = 200
 for it in range(N + 20):

@@ -8,7 +8,6 @@ the shares.  Never used by the product path; the numbers are shares, not run tim
 import ctypes
 import importlib
 import os
-import shutil
 import subprocess
 import sys
 
