@@ -53,7 +53,7 @@ int mzenv_step(mzenv *env, const int32_t *actions, float *reward_out, uint8_t *d
 int mzenv_observe(mzenv *env, float *obs_out, int32_t *legal_out, int32_t *num_legal_out, int32_t *to_play_out,
                   void *stream);
 
-/* One self-play move of every env in a single call (four launches on `stream`): Game.step(actions), the
+/* One self-play move of every env in a single call (one launch on `stream`): Game.step(actions), the
  * observation after the move (terminal observations included) -> obs_after_out, Game.reset() of the envs that
  * just finished, and the observation the next search sees -> obs_next_out (legal / num_legal / to_play outputs
  * describe that next state). */

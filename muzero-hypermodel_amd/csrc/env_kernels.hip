@@ -45,9 +45,7 @@ __device__ __forceinline__ double mt_uniform(uint32_t* key, int32_t* pos) {
     return (a * 67108864.0 + b) / 9007199254740992.0;
 }
 
-__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams p, const uint8_t* __restrict__ mask) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.E || (mask && !mask[e])) return;
+__device__ __forceinline__ void env_reset_one(const EnvParams& p, int e) {
     if (p.game == 0) {
         // numpy RandomState(seed).uniform(-0.05, 0.05, size=4): low + (high - low) * random_sample()
         uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
@@ -62,15 +60,14 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams p, const uint8
     }
 }
 
-__global__ __launch_bounds__(256) void env_step_kernel(EnvParams p, const int32_t* __restrict__ actions,
-                                                       float* __restrict__ reward_out, uint8_t* __restrict__ done_out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.E) return;
-    const int a = actions[e];
-    if (a < 0) {  // env left alone this move (e.g. its search was not run): nothing happened
+// One move of env e; returns whether the game ended.  a < 0: the env is left alone this move (e.g. its search
+// was not run) -- nothing happened.
+__device__ __forceinline__ bool env_step_one(const EnvParams& p, int e, int a, float* __restrict__ reward_out,
+                                             uint8_t* __restrict__ done_out) {
+    if (a < 0) {
         reward_out[e] = 0.f;
         done_out[e] = 0;
-        return;
+        return false;
     }
     float reward = 0.f;
     bool done = false;
@@ -119,12 +116,12 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams p, const int32_
     }
     reward_out[e] = reward;
     done_out[e] = done ? 1 : 0;
+    return done;
 }
 
-__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams p, float* __restrict__ obs, int32_t* __restrict__ legal,
-                                                          int32_t* __restrict__ num_legal, int32_t* __restrict__ to_play) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.E) return;
+__device__ __forceinline__ void env_observe_one(const EnvParams& p, int e, float* __restrict__ obs,
+                                                int32_t* __restrict__ legal, int32_t* __restrict__ num_legal,
+                                                int32_t* __restrict__ to_play) {
     float* o = obs + static_cast<size_t>(e) * p.obs_floats;
     int32_t* l = legal + static_cast<size_t>(e) * p.A;
     if (p.game == 0) {
@@ -154,12 +151,53 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams p, float* __
     to_play[e] = pl == 1 ? 0 : 1;
 }
 
+__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams p, const uint8_t* __restrict__ mask) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E || (mask && !mask[e])) return;
+    env_reset_one(p, e);
+}
+
+__global__ __launch_bounds__(256) void env_step_kernel(EnvParams p, const int32_t* __restrict__ actions,
+                                                       float* __restrict__ reward_out, uint8_t* __restrict__ done_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    env_step_one(p, e, actions[e], reward_out, done_out);
+}
+
+__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams p, float* __restrict__ obs, int32_t* __restrict__ legal,
+                                                          int32_t* __restrict__ num_legal, int32_t* __restrict__ to_play) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    env_observe_one(p, e, obs, legal, num_legal, to_play);
+}
+
+// step, observation of the position reached, reset of the envs whose game ended, observation to search next:
+// the four steps of one self-play move in one launch (envs are independent: one thread runs all four for its env).
+__global__ __launch_bounds__(256) void env_advance_kernel(EnvParams p, const int32_t* __restrict__ actions,
+                                                          float* __restrict__ reward_out, uint8_t* __restrict__ done_out,
+                                                          float* __restrict__ obs_after, float* __restrict__ obs_next,
+                                                          int32_t* __restrict__ legal, int32_t* __restrict__ num_legal,
+                                                          int32_t* __restrict__ to_play) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const bool done = env_step_one(p, e, actions[e], reward_out, done_out);
+    env_observe_one(p, e, obs_after, legal, num_legal, to_play);
+    if (done) env_reset_one(p, e);
+    env_observe_one(p, e, obs_next, legal, num_legal, to_play);
+}
+
 hipError_t launch_env_reset(const EnvParams& p, const uint8_t* mask, hipStream_t stream) {
     env_reset_kernel<<<dim3((p.E + 255) / 256), dim3(256), 0, stream>>>(p, mask);
     return hipGetLastError();
 }
 hipError_t launch_env_step(const EnvParams& p, const int32_t* actions, float* reward, uint8_t* done, hipStream_t stream) {
     env_step_kernel<<<dim3((p.E + 255) / 256), dim3(256), 0, stream>>>(p, actions, reward, done);
+    return hipGetLastError();
+}
+hipError_t launch_env_advance(const EnvParams& p, const int32_t* actions, float* reward, uint8_t* done, float* obs_after,
+                              float* obs_next, int32_t* legal, int32_t* num_legal, int32_t* to_play, hipStream_t stream) {
+    env_advance_kernel<<<dim3((p.E + 255) / 256), dim3(256), 0, stream>>>(p, actions, reward, done, obs_after, obs_next, legal,
+                                                                          num_legal, to_play);
     return hipGetLastError();
 }
 hipError_t launch_env_observe(const EnvParams& p, float* obs, int32_t* legal, int32_t* num_legal, int32_t* to_play,

@@ -11,6 +11,8 @@
 namespace mz {
 hipError_t launch_env_reset(const EnvParams& p, const uint8_t* mask, hipStream_t stream);
 hipError_t launch_env_step(const EnvParams& p, const int32_t* actions, float* reward, uint8_t* done, hipStream_t stream);
+hipError_t launch_env_advance(const EnvParams& p, const int32_t* actions, float* reward, uint8_t* done, float* obs_after,
+                              float* obs_next, int32_t* legal, int32_t* num_legal, int32_t* to_play, hipStream_t stream);
 hipError_t launch_env_observe(const EnvParams& p, float* obs, int32_t* legal, int32_t* num_legal, int32_t* to_play,
                               hipStream_t stream);
 hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
@@ -146,10 +148,8 @@ int mzenv_advance(mzenv* env, const int32_t* actions, float* reward_out, uint8_t
         !to_play_out)
         return env_fail(env, -1, "mzenv_advance: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    MZENV_HIP(env, mz::launch_env_step(env->p, actions, reward_out, done_out, stream));
-    MZENV_HIP(env, mz::launch_env_observe(env->p, obs_after_out, legal_out, num_legal_out, to_play_out, stream));
-    MZENV_HIP(env, mz::launch_env_reset(env->p, done_out, stream));
-    MZENV_HIP(env, mz::launch_env_observe(env->p, obs_next_out, legal_out, num_legal_out, to_play_out, stream));
+    MZENV_HIP(env, mz::launch_env_advance(env->p, actions, reward_out, done_out, obs_after_out, obs_next_out, legal_out,
+                                          num_legal_out, to_play_out, stream));
     return 0;
 }
 

@@ -786,7 +786,7 @@ class DeviceSelfPlay:
         obs_in = cur["obs_dev"]
         for m in range(n_moves):
             eng.moves_enqueue(obs_in.reshape(E, -1))
-            # step, terminal observation, reset of the finished envs, next observation: one call, four launches
+            # step, terminal observation, reset of the finished envs, next observation: one call, one launch
             obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
                                   ring["obs_next"][m])
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs

@@ -25,11 +25,19 @@ def main():
     ap.add_argument("--moves", type=int, default=60)
     ap.add_argument("--kinds", default="host,device")
     ap.add_argument("--batch", type=int, default=20, help="moves per host round trip of the device-batch actor")
+    ap.add_argument("--weights", default="random", choices=["random", "checkpoint"],
+                    help="checkpoint: the reference's trained CartPole weights (tests/golden/cartpole_weights.npz): long "
+                         "games and the benchmark's tree depths; random: seed-0 initialisation, games of ~15 moves")
     args = ap.parse_args()
     mod = importlib.import_module(f"muzero-hypermodel_amd.games.{args.game}")
     config = mod.MuZeroConfig()
     torch.manual_seed(0)
     weights = models.MuZeroNetwork(config).get_weights()
+    if args.weights == "checkpoint":
+        import numpy
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        fixture = numpy.load(os.path.join(root, "tests", "golden", "cartpole_weights.npz"))
+        weights = {k: torch.from_numpy(fixture[k]) for k in fixture.files}
     for kind in args.kinds.split(","):
         if kind == "host":
             actor = sp.BatchedSelfPlay({"weights": weights}, mod.Game, config, 0, args.envs)
@@ -72,7 +80,7 @@ def main():
             moves = args.moves * args.envs
         print(json.dumps({"actor": kind, "game": args.game, "envs": args.envs, "moves_per_s": moves / dt,
                           "simulations_per_s": moves * config.num_simulations / dt, "ms_per_move_step": 1e3 * dt * args.envs / moves,
-                          "games_finished": done[0]}), flush=True)
+                          "games_finished": done[0], "weights": args.weights}), flush=True)
         actor.close()
 
 
