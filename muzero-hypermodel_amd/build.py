@@ -50,5 +50,23 @@ def build_native(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_tools(force=False):
+    """Stand-alone measurement programs under tools/ (no library, no torch) -> tools/_bin/."""
+    tools = os.path.join(os.path.dirname(PKG_DIR), "tools")
+    out_dir = os.path.join(tools, "_bin")
+    os.makedirs(out_dir, exist_ok=True)
+    built = []
+    for name in ("random_access_ceiling",):
+        src, out = os.path.join(tools, name + ".hip"), os.path.join(out_dir, name)
+        if force or not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+            proc = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, src],
+                                  capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        built.append(out)
+    return built
+
+
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_tools(force=True))
