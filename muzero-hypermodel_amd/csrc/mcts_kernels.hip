@@ -50,15 +50,26 @@ template <int G, int CH, bool FUSE_GATHER>
 __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim, float* __restrict__ hidden_out,
                                                           int64_t* __restrict__ action_out) {
     extern __shared__ double pbc_table[];  // [2][S+1]
-    stage_pbc_table(pbc_table, p);
-    __syncthreads();
-
     constexpr int kTrees = kThreads / G;
     const int e = blockIdx.x * kTrees + threadIdx.x / G;
     const int j = threadIdx.x % G;
     const int group_base = threadIdx.x - j;  // lane of the group leader inside the wave
-    if (e >= p.E) return;
-    const int n_root = p.root_children[e];
+    // Per-tree control words first, the table after: at HBM scale every dependent round trip to memory costs
+    // microseconds, so the tree's own loads go out before the (cache-resident) table is staged, and the root
+    // block is touched now so that the descent's first record is on its way while the table lands in LDS.
+    const bool in_range = e < p.E;
+    int n_root = 0;
+    MinMax mm{};
+    int32_t mt_pos = 0;
+    if (in_range) {
+        n_root = p.root_children[e];
+        mm = p.min_max[e];
+        if (j == 0) mt_pos = p.mt_pos[e];
+        (void)*reinterpret_cast<const volatile int32_t*>(p.blocks + static_cast<size_t>(e) * p.block_stride + (16u * j) % p.block_stride);
+    }
+    stage_pbc_table(pbc_table, p);
+    __syncthreads();
+    if (!in_range) return;
     if (n_root == 0) {  // inactive tree: keep the batch row defined
         if (j == 0) {
             p.path_len[e] = 0;
@@ -71,8 +82,6 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
     }
 
     const GlobalTree tree = global_tree(p, e);
-    const MinMax mm = p.min_max[e];
-    int32_t mt_pos = (j == 0) ? p.mt_pos[e] : 0;
     uint32_t words = 0;
     const Descent d = descend<G, CH>(tree, pbc_table, p.S, p.A, sim, n_root, mm, p.discount, p.P == 2,
                                      p.mt_key + static_cast<size_t>(e) * kMtN, mt_pos, words, j, group_base,
