@@ -16,6 +16,14 @@ import torch
 from . import models
 
 
+def _scale_gradient(tensor, divisor):
+    """Leaves `tensor` as it is and divides the gradient flowing back through it by `divisor` (a number or a
+    per-sample tensor).  A tensor hook, not an autograd node: the graph -- and with it the order in which the
+    shared parameters accumulate their gradients -- stays the reference's, which one-step Adam parity needs."""
+    tensor.register_hook(lambda grad: grad / divisor)
+    return tensor
+
+
 class Trainer:
     def __init__(self, initial_checkpoint, config, device=None):
         self.config = config
@@ -68,73 +76,67 @@ class Trainer:
                     time.sleep(0.5)
 
     # ---- one training step (trainer.py:124-268) ---------------------------------------------------------
-    def update_weights(self, batch):
-        observation_batch, action_batch, target_value, target_reward, target_policy, weight_batch, gradient_scale_batch = batch
+    def _batch_on_device(self, batch):
+        """The seven batch entries as float32 tensors on the model's device (actions: int64 [B, K+1, 1]).  Lists and
+        numpy arrays (the reference's replay buffer) and CUDA tensors (the device replay store) are both accepted."""
         device = next(self.model.parameters()).device
 
-        def f32(x):
+        def as_tensor(x):
             if torch.is_tensor(x):
-                return x.to(device=device, dtype=torch.float32)
-            return torch.tensor(numpy.asarray(x)).float().to(device)
+                return x.to(device)
+            if isinstance(x, numpy.ndarray):
+                x = x.copy()
+            return torch.tensor(numpy.asarray(x)).to(device)
 
-        target_value = f32(target_value)
-        target_value_scalar = target_value                       # scalars kept for the new priorities
-        if self.config.PER:
-            weight_batch = f32(weight_batch.copy() if isinstance(weight_batch, numpy.ndarray) else weight_batch)
-        observation_batch = f32(observation_batch)
-        action_batch = (action_batch.to(device) if torch.is_tensor(action_batch)
-                        else torch.tensor(numpy.asarray(action_batch)).to(device)).long().unsqueeze(-1)
-        target_reward = f32(target_reward)
-        target_policy = f32(target_policy)
-        gradient_scale_batch = f32(gradient_scale_batch)
-        priorities = torch.zeros_like(target_value_scalar)
+        observations, actions, values, rewards, policies, weights, gradient_scales = batch
+        return {"observations": as_tensor(observations).float(), "actions": as_tensor(actions).long().unsqueeze(-1),
+                "values": as_tensor(values).float(), "rewards": as_tensor(rewards).float(),
+                "policies": as_tensor(policies).float(),
+                "weights": as_tensor(weights).float() if self.config.PER else None,
+                "gradient_scales": as_tensor(gradient_scales).float()}
 
-        target_value = models.scalar_to_support(target_value, self.config.support_size)
-        target_reward = models.scalar_to_support(target_reward, self.config.support_size)
+    def _unroll(self, observations, actions):
+        """(value logits, reward logits, policy logits) per unroll step; the hidden state handed from step to step
+        passes half of its gradient on (paper appendix "Training", trainer.py:171-173)."""
+        out = self.model.initial_inference(observations)
+        steps, hidden = [out[:3]], out[3]
+        for k in range(1, actions.shape[1]):
+            out = self.model.recurrent_inference(hidden, actions[:, k])
+            hidden = _scale_gradient(out[3], 2.0)
+            steps.append(out[:3])
+        return steps
 
-        # predictions along the unroll (the 0.5 hook: paper appendix Training, trainer.py:171-173)
-        value, reward, policy_logits, hidden_state = self.model.initial_inference(observation_batch)
-        predictions = [(value, reward, policy_logits)]
-        for i in range(1, action_batch.shape[1]):
-            value, reward, policy_logits, hidden_state = self.model.recurrent_inference(hidden_state, action_batch[:, i])
-            hidden_state.register_hook(lambda grad: grad * 0.5)
-            predictions.append((value, reward, policy_logits))
+    def update_weights(self, batch):
+        cfg = self.config
+        b = self._batch_on_device(batch)
+        value_targets = models.scalar_to_support(b["values"], cfg.support_size)
+        reward_targets = models.scalar_to_support(b["rewards"], cfg.support_size)
+        priorities = torch.zeros_like(b["values"])
+        sums = {"value": 0, "reward": 0, "policy": 0}
+        for k, (value, reward, policy_logits) in enumerate(self._unroll(b["observations"], b["actions"])):
+            per_head = dict(zip(("value", "reward", "policy"), self.loss_function(
+                value.squeeze(-1), reward.squeeze(-1), policy_logits, value_targets[:, k], reward_targets[:, k],
+                b["policies"][:, k])))
+            if k == 0:
+                del per_head["reward"]           # no reward is predicted for the root position (trainer.py:182-193)
+            for head, term in per_head.items():
+                if k > 0:                        # every unrolled step contributes 1 / (its gradient scale) of its gradient
+                    term = _scale_gradient(term, b["gradient_scales"][:, k])
+                sums[head] = sums[head] + term
+            with torch.no_grad():                # new priorities: |predicted value - target| ** alpha (trainer.py:199-209)
+                predicted = models.support_to_scalar(value, cfg.support_size).squeeze(-1)
+                priorities[:, k] = torch.abs(predicted - b["values"][:, k]) ** cfg.PER_alpha
 
-        value_loss, reward_loss, policy_loss = (0, 0, 0)
-        value, reward, policy_logits = predictions[0]
-        current_value_loss, _, current_policy_loss = self.loss_function(
-            value.squeeze(-1), reward.squeeze(-1), policy_logits, target_value[:, 0], target_reward[:, 0], target_policy[:, 0])
-        value_loss += current_value_loss
-        policy_loss += current_policy_loss
-        with torch.no_grad():
-            predicted = models.support_to_scalar(value, self.config.support_size).squeeze(-1)
-            priorities[:, 0] = torch.abs(predicted - target_value_scalar[:, 0]) ** self.config.PER_alpha
-        for i in range(1, len(predictions)):
-            value, reward, policy_logits = predictions[i]
-            current_value_loss, current_reward_loss, current_policy_loss = self.loss_function(
-                value.squeeze(-1), reward.squeeze(-1), policy_logits, target_value[:, i], target_reward[:, i],
-                target_policy[:, i])
-            scale = gradient_scale_batch[:, i]
-            current_value_loss.register_hook(lambda grad, scale=scale: grad / scale)
-            current_reward_loss.register_hook(lambda grad, scale=scale: grad / scale)
-            current_policy_loss.register_hook(lambda grad, scale=scale: grad / scale)
-            value_loss += current_value_loss
-            reward_loss += current_reward_loss
-            policy_loss += current_policy_loss
-            with torch.no_grad():
-                predicted = models.support_to_scalar(value, self.config.support_size).squeeze(-1)
-                priorities[:, i] = torch.abs(predicted - target_value_scalar[:, i]) ** self.config.PER_alpha
-
-        loss = value_loss * self.config.value_loss_weight + reward_loss + policy_loss
-        if self.config.PER:
-            loss *= weight_batch
+        loss = sums["value"] * cfg.value_loss_weight + sums["reward"] + sums["policy"]
+        if cfg.PER:
+            loss = loss * b["weights"]           # importance-sampling correction of the prioritised replay
         loss = loss.mean()
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()
         self.training_step += 1
-        return (priorities.detach().cpu().numpy(), loss.item(), value_loss.mean().item(), reward_loss.mean().item(),
-                policy_loss.mean().item())
+        return (priorities.detach().cpu().numpy(), loss.item(), sums["value"].mean().item(),
+                sums["reward"].mean().item(), sums["policy"].mean().item())
 
     def update_lr(self):
         lr = self.config.lr_init * self.config.lr_decay_rate ** (self.training_step / self.config.lr_decay_steps)
