@@ -287,6 +287,16 @@ int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *ac
 int mzmcts_moves_ring(mzmcts_engine *engine, void **host_base, int64_t *move_stride, int64_t *offsets,
                       int32_t *capacity_moves);
 
+/* ---- residual-network epilogue (no engine: any device tensor of the current device) ---------
+ * What follows every convolution of the reference's residual networks in eval() -- BatchNorm2d with its
+ * running statistics, the residual add, ReLU (models.py:215-237 ResidualBlock.forward; 318-335, 467-480) --
+ * in one launch:   out = act(x * scale[c] + shift[c] (+ residual)),   c = (index / plane) % channels
+ * over a contiguous NCHW tensor of `count` floats (plane = H*W; scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale, both dev f32[channels]).  residual may be NULL; relu: 0 = identity.
+ * x / residual / out must be 16-byte aligned; out must not alias x.  No allocation, no synchronisation. */
+int mzmcts_affine_act(const float *x, const float *scale, const float *shift, const float *residual, float *out,
+                      int64_t count, int32_t channels, int32_t plane, int32_t relu, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

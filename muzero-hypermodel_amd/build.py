@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
-SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip"]
+SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip"]
 HEADERS = ["np_legacy_rng.h", "tree_layout.h", "tree_device.h", "fc_net_device.h", "narrow_device.h", "kernel_common.h", "env_layout.h", os.path.join("..", "..", "include", "mzmcts.h"),
            os.path.join("..", "..", "include", "mzenv.h"), os.path.join("..", "..", "include", "mzreplay.h"), os.path.join("..", "..", "include", "mzhist.h")]
 

@@ -18,6 +18,8 @@ import math
 
 import torch
 
+from . import _native
+
 
 class MuZeroNetwork:
     """Factory, reference models.py:7-41."""
@@ -196,12 +198,43 @@ class BatchNorm2d(torch.nn.BatchNorm2d):
             torch.sub(self.bias, self.running_mean * self._scale, out=self._shift)
         self._folded = self._fold_key()
 
+    def folded(self):
+        """(scale, shift) of the eval-mode affine, refreshed if the parameters changed."""
+        if getattr(self, "_folded", None) != self._fold_key():
+            self.refold()
+        return self._scale, self._shift
+
     def forward(self, x):
         if self.training:
             return super().forward(x)
-        if getattr(self, "_folded", None) != self._fold_key():
-            self.refold()
-        return torch.addcmul(self._shift.view(1, -1, 1, 1), x, self._scale.view(1, -1, 1, 1))
+        scale, shift = self.folded()
+        return torch.addcmul(shift.view(1, -1, 1, 1), x, scale.view(1, -1, 1, 1))
+
+
+def conv_epilogue(x, bn, residual=None):
+    """relu(bn(x) [+ residual]) after a convolution (reference models.py:215-237).  Inference on the GPU: one HIP
+    launch (include/mzmcts.h mzmcts_affine_act) instead of torch's three element-wise ones, same operations in
+    the same order; training, autograd and CPU tensors take the torch expression."""
+    native = (x.is_cuda and not bn.training and x.dtype == torch.float32 and x.dim() == 4
+              and not (torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))))
+    if not native:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y)
+    scale, shift = bn.folded()
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _native.load().mzmcts_affine_act(
+            x.data_ptr(), scale.data_ptr(), shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+            out.data_ptr(), x.numel(), x.shape[1], x.shape[2] * x.shape[3], 1,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"mzmcts_affine_act failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+    return out
 
 
 class PointwiseConv2d(torch.nn.Conv2d):
@@ -234,10 +267,8 @@ class ResidualBlock(torch.nn.Module):
         self.bn2 = BatchNorm2d(num_channels)
 
     def forward(self, x):
-        y = torch.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        y += x
-        return torch.relu(y)
+        y = conv_epilogue(self.conv1(x), self.bn1)
+        return conv_epilogue(self.conv2(y), self.bn2, residual=x)
 
 
 def _tower(channels, count):
@@ -308,7 +339,7 @@ class RepresentationNetwork(torch.nn.Module):
         self.resblocks = _tower(num_channels, num_blocks)
 
     def forward(self, x):
-        x = self.downsample_net(x) if self.downsample else torch.relu(self.bn(self.conv(x)))
+        x = self.downsample_net(x) if self.downsample else conv_epilogue(self.conv(x), self.bn)
         for block in self.resblocks:
             x = block(x)
         return x
@@ -326,7 +357,7 @@ class DynamicsNetwork(torch.nn.Module):
         self.fc = mlp(block_output_size_reward, fc_reward_layers, full_support_size)
 
     def forward(self, x):
-        x = torch.relu(self.bn(self.conv(x)))
+        x = conv_epilogue(self.conv(x), self.bn)
         for block in self.resblocks:
             x = block(x)
         reward = self.fc(self.conv1x1_reward(x).reshape(-1, self.block_output_size_reward))

@@ -4,7 +4,9 @@ other BASELINE.json configs: TicTacToe ResNet (25 sims, masked roots), Connect4 
 Atari-like 84x84x4 CNN representation (50 sims).  Synthetic weights (tests/golden/synth.py), synthetic
 observations, Dirichlet noise on.  One JSON line per config.
 
-    python tools/bench_configs.py [tictactoe:4096 connect4:1024 atari84:1024] [--moves 20]
+    python tools/bench_configs.py [tictactoe:4096 connect4:1024 atari84:1024] [--moves 20] [--warm 3] [--no-graph]
+
+(--no-graph --warm 1 --moves 1 is the form profiled under rocprofv3 --pmc: eager launches, few of them.)
 """
 import importlib, json, os, sys, time
 import numpy as np, torch
@@ -23,6 +25,8 @@ if "--miopen-find" in sys.argv:
     torch.backends.cudnn.benchmark = True
 args = [a for a in sys.argv[1:] if not a.startswith("--") and ":" in a] or ["tictactoe:4096", "connect4:1024", "atari84:1024"]
 moves = int(sys.argv[sys.argv.index("--moves") + 1]) if "--moves" in sys.argv else 20
+warm = int(sys.argv[sys.argv.index("--warm") + 1]) if "--warm" in sys.argv else 3
+use_graph = "--no-graph" not in sys.argv
 for spec in args:
     name, E = spec.split(":"); E = int(E)
     cfg = config_of(name)
@@ -41,8 +45,8 @@ for spec in args:
         n = A if len(cfg.players) == 1 else int(rs.randint(max(1, A // 2), A))
         acts = np.sort(rs.choice(A, size=n, replace=False)); legal[e, :n] = acts; nl[e] = n
     tp = rs.randint(0, len(cfg.players), E).astype(np.int32)
-    engine = eng.BatchedMCTS(cfg, E, use_graph=True)
-    for _ in range(3):
+    engine = eng.BatchedMCTS(cfg, E, use_graph=use_graph)
+    for _ in range(warm):
         engine.search(model, obs, legal, tp, True, num_legal=nl); engine.sample_actions(1.0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(moves):
