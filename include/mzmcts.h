@@ -297,6 +297,12 @@ int mzmcts_moves_ring(mzmcts_engine *engine, void **host_base, int64_t *move_str
 int mzmcts_affine_act(const float *x, const float *scale, const float *shift, const float *residual, float *out,
                       int64_t count, int32_t channels, int32_t plane, int32_t relu, void *stream);
 
+/* The hidden-state rescale of the residual networks (models.py:525-549, 586-602): every row of `row_len`
+ * floats (one (sample, channel) board plane) becomes (x - min) / span, span = max - min (+ 1e-5 when below
+ * 1e-5).  x, out: dev f32[rows, row_len] contiguous, out may be x.  row_len <= 128.  One launch instead of
+ * torch's seven; same fp32 operations, bit-identical results.  No allocation, no synchronisation. */
+int mzmcts_unit_rescale(const float *x, float *out, int64_t rows, int32_t row_len, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

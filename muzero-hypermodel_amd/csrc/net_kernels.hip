@@ -57,7 +57,56 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     }
 }
 
+// Min-max rescale of every row to [0, 1] (reference models.py:525-549: per (sample, channel) over the board):
+//     out = (x - min(row)) / span,   span = max(row) - min(row), + 1e-5 if it is below 1e-5
+// torch spells it amin, amax, sub, lt, add, where, div (seven launches).  A workgroup moves a tile of 256 rows
+// through LDS with coalesced accesses on both sides; one thread owns a row in between.  Same fp32 operations as the
+// torch expression (IEEE subtraction and division), so the result is bit-identical to it; NaNs propagate as
+// torch.amin / amax propagate them.  x may be the same tensor as out (the tile is read whole before it is written).
+constexpr int kRescaleRows = 256;
+
+__global__ __launch_bounds__(kRescaleRows) void unit_rescale_kernel(const float* x, float* out, uint32_t rows,
+                                                                    uint32_t row_len) {
+    extern __shared__ float tile[];  // [kRescaleRows][row_len]
+    const uint32_t first_row = blockIdx.x * kRescaleRows;
+    const uint32_t n_rows = min(static_cast<uint32_t>(kRescaleRows), rows - first_row);
+    const size_t base = static_cast<size_t>(first_row) * row_len;
+    const uint32_t n = n_rows * row_len;
+    for (uint32_t i = threadIdx.x; i < n; i += kRescaleRows) tile[i] = x[base + i];
+    __syncthreads();
+    if (threadIdx.x < n_rows) {
+        float* row = tile + threadIdx.x * row_len;
+        float lo = row[0], hi = row[0];
+        for (uint32_t p = 1; p < row_len; ++p) {
+            const float v = row[p];
+            lo = (v < lo || v != v) ? v : lo;
+            hi = (v > hi || v != v) ? v : hi;
+        }
+        float span = hi - lo;
+        if (span < 1e-5f) span = span + 1e-5f;
+        for (uint32_t p = 0; p < row_len; ++p) row[p] = (row[p] - lo) / span;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kRescaleRows) out[base + i] = tile[i];
+}
+
 }  // namespace mz
+
+extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int32_t row_len, void* stream_) {
+    if (!x || !out || rows < 0 || rows > 0x7fffffff || row_len <= 0 || row_len > 128) return MZMCTS_ERR_INVALID;
+    if (rows == 0) return MZMCTS_OK;
+    const size_t lds = sizeof(float) * mz::kRescaleRows * static_cast<size_t>(row_len);  // <= 128 KB
+    const dim3 grid(static_cast<unsigned>((rows + mz::kRescaleRows - 1) / mz::kRescaleRows));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (lds > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(mz::unit_rescale_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (err != hipSuccess) return MZMCTS_ERR_HIP;
+    }
+    mz::unit_rescale_kernel<<<grid, dim3(mz::kRescaleRows), lds, stream>>>(x, out, static_cast<uint32_t>(rows),
+                                                                          static_cast<uint32_t>(row_len));
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
 
 extern "C" int mzmcts_affine_act(const float* x, const float* scale, const float* shift, const float* residual, float* out,
                                  int64_t count, int32_t channels, int32_t plane, int32_t relu, void* stream_) {

@@ -88,6 +88,28 @@ def _unit_rescale(x, dims):
     return x - low, span
 
 
+def board_rescale(raw, out=None):
+    """Min-max rescale of every (sample, channel) board plane of an NCHW tensor to [0, 1] (reference
+    models.py:525-549, 586-602), into `out` if given.  Inference on the GPU: one HIP launch
+    (include/mzmcts.h mzmcts_unit_rescale), bit-identical to the torch expression below, which training, autograd
+    and CPU tensors take."""
+    plane = raw.shape[2] * raw.shape[3]
+    native = (raw.is_cuda and raw.dtype == torch.float32 and plane <= 128 and not (torch.is_grad_enabled() and raw.requires_grad)
+              and (out is None or (out.is_contiguous() and out.dtype == torch.float32 and out.shape == raw.shape)))
+    if not native:
+        shifted, span = _unit_rescale(raw, (2, 3))
+        return torch.div(shifted, span, out=out)
+    raw = raw.contiguous()
+    if out is None:
+        out = torch.empty_like(raw)
+    with torch.cuda.device(raw.device):
+        rc = _native.load().mzmcts_unit_rescale(raw.data_ptr(), out.data_ptr(), raw.shape[0] * raw.shape[1], plane,
+                                                torch.cuda.current_stream(raw.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"mzmcts_unit_rescale failed ({rc}) on a tensor of shape {tuple(raw.shape)}")
+    return out
+
+
 class AbstractNetwork(torch.nn.Module):
     """reference models.py:56-73"""
 
@@ -411,17 +433,14 @@ class MuZeroResidualNetwork(AbstractNetwork):
         return self.prediction_network(encoded_state)
 
     def representation(self, observation):
-        raw = self.representation_network(observation)
-        shifted, span = _unit_rescale(raw, (2, 3))  # per (sample, channel) over the board
-        return shifted / span
+        return board_rescale(self.representation_network(observation))
 
     def dynamics(self, encoded_state, action, out_state=None):
         b, _, h, w = encoded_state.shape
         plane = (action.to(encoded_state.dtype) / self.action_space_size)[:, :, None, None]
         x = torch.cat((encoded_state, plane.expand(b, 1, h, w)), dim=1)
         raw, reward = self.dynamics_network(x)
-        shifted, span = _unit_rescale(raw, (2, 3))
-        return torch.div(shifted, span, out=out_state), reward
+        return board_rescale(raw, out=out_state), reward
 
     def initial_inference(self, observation):
         encoded_state = self.representation(observation)

@@ -54,3 +54,29 @@ def test_conv_epilogue_keeps_autograd_and_training_on_torch(pkg):
         a = block(x)
     b = block(x)
     assert torch.allclose(a, b.detach(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4096, 16, 3, 3), (1024, 64, 6, 7), (5, 3, 1, 1), (300, 7, 6, 6), (2, 2, 8, 16)])
+def test_board_rescale_equals_torch_expression(pkg, shape):
+    """include/mzmcts.h mzmcts_unit_rescale == the reference's per-plane min-max rescale (models.py:525-549),
+    bit for bit: flat planes (span < 1e-5), NaNs, a ragged last tile, writing into a given tensor and in place."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    torch.manual_seed(sum(shape))
+    raw = torch.randn(shape, device="cuda") * 3
+    raw[0, 0] = 0.25                                   # a flat plane: span 0 -> 1e-5
+    if shape[0] > 2:
+        raw[1, 1] = raw[1, 1] * 1e-7                   # a nearly flat one
+        raw[2, 0, 0, 0] = float("nan")
+    with torch.no_grad():
+        shifted, span = models._unit_rescale(raw, (2, 3))
+        want = (shifted / span).cpu().numpy()
+        got = models.board_rescale(raw)
+        into = torch.full(shape, -7.0, device="cuda")
+        assert models.board_rescale(raw, out=into) is into
+        in_place = raw.clone()
+        models.board_rescale(in_place, out=in_place)
+    for result in (got, into, in_place):
+        assert np.array_equal(result.cpu().numpy(), want, equal_nan=True)
+    live = raw.clone().requires_grad_(True)            # with autograd: the torch expression
+    models.board_rescale(live).sum().backward()
+    assert live.grad is not None
