@@ -303,6 +303,19 @@ int mzmcts_affine_act(const float *x, const float *scale, const float *shift, co
  * torch's seven; same fp32 operations, bit-identical results.  No allocation, no synchronisation. */
 int mzmcts_unit_rescale(const float *x, float *out, int64_t rows, int32_t row_len, void *stream);
 
+/* One reward / value / policy head of the residual networks (models.py:467-480, 500-522): 1x1 convolution with
+ * bias over the board, flatten, Linear, ELU, Linear -> logits, in one launch.  Pointers are the torch
+ * parameters themselves (dev f32, read at every launch, so an in-place weight refresh is seen):
+ *   conv_w [reduced, channels], conv_b [reduced], fc1_w [hidden, reduced*plane], fc1_b [hidden],
+ *   fc2_w [outputs, hidden], fc2_b [outputs];   x dev f32[batch, channels, plane] (16-byte aligned),
+ *   out dev f32[batch, outputs].  MZMCTS_ERR_INVALID when the head does not fit in LDS (the caller keeps the
+ * torch modules for that).  fp32, sums in index order: equal to the torch modules to fp32 rounding. */
+typedef struct mzmcts_head_desc {
+    const float *conv_w, *conv_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    int32_t channels, plane, reduced, hidden, outputs;
+} mzmcts_head_desc;
+int mzmcts_conv_head(const float *x, const mzmcts_head_desc *head, float *out, int64_t batch, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
+    "mzmcts_conv_head": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "mzmcts_unit_rescale": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int32, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
@@ -194,6 +195,13 @@ def check(lib, engine, rc):
     if rc == ERR_PLAYERS:
         raise NotImplementedError(msg)
     raise RuntimeError(msg)
+
+
+class MzHeadDesc(ctypes.Structure):
+    """mzmcts_head_desc (include/mzmcts.h): one reward / value / policy head of the residual networks."""
+    _fields_ = [("conv_w", c_void), ("conv_b", c_void), ("fc1_w", c_void), ("fc1_b", c_void), ("fc2_w", c_void),
+                ("fc2_b", c_void), ("channels", ctypes.c_int32), ("plane", ctypes.c_int32), ("reduced", ctypes.c_int32),
+                ("hidden", ctypes.c_int32), ("outputs", ctypes.c_int32)]
 
 
 class MzHistMoves(ctypes.Structure):

@@ -8,6 +8,7 @@
 // built with -ffp-contract=off), so the results are bit-identical to it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "../../include/mzmcts.h"
@@ -90,6 +91,94 @@ __global__ __launch_bounds__(kRescaleRows) void unit_rescale_kernel(const float*
     for (uint32_t i = threadIdx.x; i < n; i += kRescaleRows) out[base + i] = tile[i];
 }
 
+// One prediction / reward head of the residual networks (reference models.py:467-480 reward, 500-522 value and
+// policy): 1x1 convolution (+ bias) over the board, flatten, Linear, ELU, Linear -- six launches through torch (two
+// of them layout copies around the 1x1 GEMM), one here.  A wave owns a sample: its board goes to LDS once, the three
+// layers run out of LDS (weights staged per workgroup, the Linear weights transposed so that lanes read consecutive
+// words), only the logits are written.  fp32 throughout; sums run in index order (hipBLASLt's order is its own, so
+// the two agree to fp32 rounding, not bit for bit -- tests/test_gpu_net.py holds them to 1e-5).
+constexpr int kHeadWaves = 4;
+
+struct HeadShape {
+    int C, P, R, Hd, O;  // channels, board positions, reduced channels, hidden units, outputs
+    __host__ __device__ int conv_w() const { return 0; }
+    __host__ __device__ int conv_b() const { return conv_w() + R * C; }
+    __host__ __device__ int fc1_w() const { return conv_b() + R; }           // [R*P][Hd]  (transposed)
+    __host__ __device__ int fc1_b() const { return fc1_w() + R * P * Hd; }
+    __host__ __device__ int fc2_w() const { return fc1_b() + Hd; }           // [Hd][O]    (transposed)
+    __host__ __device__ int fc2_b() const { return fc2_w() + Hd * O; }
+    __host__ __device__ int per_wave() const { return fc2_b() + O; }         // then kHeadWaves x [x C*P | y R*P | h Hd]
+    __host__ __device__ int wave_floats() const { return C * P + R * P + Hd; }
+    __host__ __device__ int total() const { return per_wave() + kHeadWaves * wave_floats(); }
+};
+
+__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float* __restrict__ x, mzmcts_head_desc d,
+                                                                     HeadShape s, float* __restrict__ out, int batch) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RP = s.R * s.P;
+    for (int i = tid; i < s.R * s.C; i += blockDim.x) lds[s.conv_w() + i] = d.conv_w[i];
+    for (int i = tid; i < s.R; i += blockDim.x) lds[s.conv_b() + i] = d.conv_b[i];
+    for (int i = tid; i < RP * s.Hd; i += blockDim.x) {  // source [Hd][RP] read in order, written transposed
+        const int j = i / RP, k = i - j * RP;
+        lds[s.fc1_w() + k * s.Hd + j] = d.fc1_w[i];
+    }
+    for (int i = tid; i < s.Hd; i += blockDim.x) lds[s.fc1_b() + i] = d.fc1_b[i];
+    for (int i = tid; i < s.Hd * s.O; i += blockDim.x) {  // source [O][Hd]
+        const int o = i / s.Hd, j = i - o * s.Hd;
+        lds[s.fc2_w() + j * s.O + o] = d.fc2_w[i];
+    }
+    for (int i = tid; i < s.O; i += blockDim.x) lds[s.fc2_b() + i] = d.fc2_b[i];
+    float* xs = lds + s.per_wave() + wave * s.wave_floats();
+    float* ys = xs + s.C * s.P;
+    float* hs = ys + RP;
+    const int CP = s.C * s.P;
+    // every wave runs the same number of rounds (the barriers are workgroup-wide); a wave without a sample idles
+    for (int first = blockIdx.x * kHeadWaves; first < batch; first += gridDim.x * kHeadWaves) {
+        const int b = first + wave;
+        const bool live = b < batch;
+        __syncthreads();  // weights staged / the previous round's buffers are free
+        if (live) {
+            const float* src = x + static_cast<size_t>(b) * CP;
+            if ((CP & 3) == 0) {
+                for (int i = lane; i < CP / 4; i += 64)
+                    reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(src)[i];
+            } else {
+                for (int i = lane; i < CP; i += 64) xs[i] = src[i];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int idx = lane; idx < RP; idx += 64) {  // 1x1 convolution: y[r][p] = b[r] + sum_c w[r][c] x[c][p]
+                const int r = idx / s.P, p = idx - r * s.P;
+                const float* w = lds + s.conv_w() + r * s.C;
+                float acc = 0.f;
+                for (int c = 0; c < s.C; ++c) acc += w[c] * xs[c * s.P + p];
+                ys[idx] = acc + lds[s.conv_b() + r];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int j = lane; j < s.Hd; j += 64) {  // Linear + ELU
+                const float* w = lds + s.fc1_w() + j;
+                float acc = 0.f;
+                for (int k = 0; k < RP; ++k) acc += w[k * s.Hd] * ys[k];
+                acc += lds[s.fc1_b() + j];
+                hs[j] = acc > 0.f ? acc : expf(acc) - 1.f;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int o = lane; o < s.O; o += 64) {  // Linear
+                const float* w = lds + s.fc2_w() + o;
+                float acc = 0.f;
+                for (int j = 0; j < s.Hd; ++j) acc += w[j * s.O] * hs[j];
+                out[static_cast<size_t>(b) * s.O + o] = acc + lds[s.fc2_b() + o];
+            }
+        }
+    }
+}
+
 }  // namespace mz
 
 extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int32_t row_len, void* stream_) {
@@ -105,6 +194,27 @@ extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int
     }
     mz::unit_rescale_kernel<<<grid, dim3(mz::kRescaleRows), lds, stream>>>(x, out, static_cast<uint32_t>(rows),
                                                                           static_cast<uint32_t>(row_len));
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float* out, int64_t batch, void* stream_) {
+    if (!x || !d || !out || !d->conv_w || !d->conv_b || !d->fc1_w || !d->fc1_b || !d->fc2_w || !d->fc2_b || batch < 0 ||
+        batch > 0x7fffffff || d->channels <= 0 || d->plane <= 0 || d->reduced <= 0 || d->hidden <= 0 || d->outputs <= 0)
+        return MZMCTS_ERR_INVALID;
+    const mz::HeadShape s{d->channels, d->plane, d->reduced, d->hidden, d->outputs};
+    const size_t lds = sizeof(float) * static_cast<size_t>(s.total());
+    if (lds > 160 * 1024 || (reinterpret_cast<uintptr_t>(x) & 15u)) return MZMCTS_ERR_INVALID;  // caller falls back
+    if (batch == 0) return MZMCTS_OK;
+    if (lds > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(mz::conv_head_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (err != hipSuccess) return MZMCTS_ERR_HIP;
+    }
+    const int64_t rounds = (batch + mz::kHeadWaves - 1) / mz::kHeadWaves;
+    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
+    const dim3 grid(static_cast<unsigned>(std::min<int64_t>(rounds, 256 * per_cu)));
+    mz::conv_head_kernel<<<grid, dim3(64 * mz::kHeadWaves), lds, static_cast<hipStream_t>(stream_)>>>(
+        x, *d, s, out, static_cast<int>(batch));
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 

@@ -14,6 +14,7 @@ Differences that matter on the GPU hot path (values are unchanged):
     engine's hidden-state pool slab, saving a copy per simulation;
   * `support_to_scalar` keeps its support vector resident instead of rebuilding it per call.
 """
+import ctypes
 import math
 
 import torch
@@ -275,6 +276,32 @@ class PointwiseConv2d(torch.nn.Conv2d):
         return out.view(b, h, w, self.out_channels).permute(0, 3, 1, 2)
 
 
+def conv_head(x, conv, fc, flat_size):
+    """fc(conv(x).reshape(-1, flat_size)): a reward / value / policy head (reference models.py:467-480, 500-522).
+    Inference on the GPU with the usual one-hidden-layer MLP: one HIP launch (include/mzmcts.h mzmcts_conv_head)
+    reading the modules' own parameters; anything else (training, autograd, CPU, deeper MLPs, heads too large
+    for LDS) evaluates the torch modules."""
+    native = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled()
+              and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and isinstance(fc[1], torch.nn.ELU)
+              and fc[1].alpha == 1.0 and isinstance(fc[2], torch.nn.Linear) and isinstance(fc[3], torch.nn.Identity)
+              and conv.bias is not None)
+    if native:
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        desc = _native.MzHeadDesc(conv.weight.data_ptr(), conv.bias.data_ptr(), fc[0].weight.data_ptr(),
+                                  fc[0].bias.data_ptr(), fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), c, h * w,
+                                  conv.out_channels, fc[0].out_features, fc[2].out_features)
+        out = torch.empty((b, fc[2].out_features), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _native.load().mzmcts_conv_head(x.data_ptr(), ctypes.addressof(desc), out.data_ptr(), b,
+                                                 torch.cuda.current_stream(x.device).cuda_stream)
+        if rc == 0:
+            return out
+        if rc != -1:                                   # -1: the head does not fit in LDS -> torch modules
+            raise RuntimeError(f"mzmcts_conv_head failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+    return fc(conv(x).reshape(-1, flat_size))
+
+
 def conv3x3(in_channels, out_channels, stride=1):
     return torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1,
                            bias=False)
@@ -382,7 +409,7 @@ class DynamicsNetwork(torch.nn.Module):
         x = conv_epilogue(self.conv(x), self.bn)
         for block in self.resblocks:
             x = block(x)
-        reward = self.fc(self.conv1x1_reward(x).reshape(-1, self.block_output_size_reward))
+        reward = conv_head(x, self.conv1x1_reward, self.fc, self.block_output_size_reward)
         return x, reward
 
 
@@ -402,8 +429,8 @@ class PredictionNetwork(torch.nn.Module):
     def forward(self, x):
         for block in self.resblocks:
             x = block(x)
-        value = self.fc_value(self.conv1x1_value(x).reshape(-1, self.block_output_size_value))
-        policy = self.fc_policy(self.conv1x1_policy(x).reshape(-1, self.block_output_size_policy))
+        value = conv_head(x, self.conv1x1_value, self.fc_value, self.block_output_size_value)
+        policy = conv_head(x, self.conv1x1_policy, self.fc_policy, self.block_output_size_policy)
         return policy, value
 
 
