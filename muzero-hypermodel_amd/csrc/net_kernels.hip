@@ -94,45 +94,64 @@ __global__ __launch_bounds__(kRescaleRows) void unit_rescale_kernel(const float*
 // One prediction / reward head of the residual networks (reference models.py:467-480 reward, 500-522 value and
 // policy): 1x1 convolution (+ bias) over the board, flatten, Linear, ELU, Linear -- six launches through torch (two
 // of them layout copies around the 1x1 GEMM), one here.  A wave owns a sample: its board goes to LDS once, the three
-// layers run out of LDS (weights staged per workgroup, the Linear weights transposed so that lanes read consecutive
-// words), only the logits are written.  fp32 throughout; sums run in index order (hipBLASLt's order is its own, so
-// the two agree to fp32 rounding, not bit for bit -- tests/test_gpu_net.py holds them to 1e-5).
+// layers run out of LDS, only the logits are written.  The weights are staged per workgroup as plain copies (many
+// loads in flight per thread: the staging is latency, not bandwidth); a lane that owns output row j of a Linear
+// layer starts its dot product at column j and wraps around, so that the 64 rows' reads fall into 64 different
+// banks whatever the row length.  A hidden layer narrower than the wave splits its dot products over the idle
+// lanes.  fp32 throughout; hipBLASLt's
+// summation order is its own, so the two agree to fp32 rounding, not bit for bit (tests/test_gpu_net.py: 1e-5).
 constexpr int kHeadWaves = 4;
 
 struct HeadShape {
     int C, P, R, Hd, O;  // channels, board positions, reduced channels, hidden units, outputs
+    int split;           // lanes sharing one hidden unit's dot product: 64 / pow2(Hd), at least 1
+    __host__ __device__ int RP() const { return R * P; }
     __host__ __device__ int conv_w() const { return 0; }
     __host__ __device__ int conv_b() const { return conv_w() + R * C; }
-    __host__ __device__ int fc1_w() const { return conv_b() + R; }           // [R*P][Hd]  (transposed)
-    __host__ __device__ int fc1_b() const { return fc1_w() + R * P * Hd; }
-    __host__ __device__ int fc2_w() const { return fc1_b() + Hd; }           // [Hd][O]    (transposed)
-    __host__ __device__ int fc2_b() const { return fc2_w() + Hd * O; }
-    __host__ __device__ int per_wave() const { return fc2_b() + O; }         // then kHeadWaves x [x C*P | y R*P | h Hd]
-    __host__ __device__ int wave_floats() const { return C * P + R * P + Hd; }
+    __host__ __device__ int fc1_w() const { return conv_b() + R; }
+    __host__ __device__ int fc1_b() const { return fc1_w() + Hd * RP(); }
+    __host__ __device__ int fc2_w() const { return fc1_b() + Hd; }
+    __host__ __device__ int fc2_b() const { return fc2_w() + O * Hd; }
+    __host__ __device__ int per_wave() const { return (fc2_b() + O + 3) & ~3; }  // 16-byte aligned boards
+    // per wave: [x C*P | y R*P | partial sums split*Hd | h Hd], padded to a multiple of 4 words
+    __host__ __device__ int wave_floats() const { return (C * P + RP() + split * Hd + Hd + 3) & ~3; }
     __host__ __device__ int total() const { return per_wave() + kHeadWaves * wave_floats(); }
 };
+
+// dst[0..n) = src[0..n) by the whole workgroup, eight independent loads per thread in flight
+__device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n, int tid) {
+    constexpr int kInFlight = 8, kThreads = 64 * kHeadWaves;
+    for (int base = tid; base < n; base += kThreads * kInFlight) {
+        float v[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int i = base + u * kThreads;
+            v[u] = i < n ? src[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int i = base + u * kThreads;
+            if (i < n) dst[i] = v[u];
+        }
+    }
+}
 
 __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float* __restrict__ x, mzmcts_head_desc d,
                                                                      HeadShape s, float* __restrict__ out, int batch) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int RP = s.R * s.P;
-    for (int i = tid; i < s.R * s.C; i += blockDim.x) lds[s.conv_w() + i] = d.conv_w[i];
-    for (int i = tid; i < s.R; i += blockDim.x) lds[s.conv_b() + i] = d.conv_b[i];
-    for (int i = tid; i < RP * s.Hd; i += blockDim.x) {  // source [Hd][RP] read in order, written transposed
-        const int j = i / RP, k = i - j * RP;
-        lds[s.fc1_w() + k * s.Hd + j] = d.fc1_w[i];
-    }
-    for (int i = tid; i < s.Hd; i += blockDim.x) lds[s.fc1_b() + i] = d.fc1_b[i];
-    for (int i = tid; i < s.Hd * s.O; i += blockDim.x) {  // source [O][Hd]
-        const int o = i / s.Hd, j = i - o * s.Hd;
-        lds[s.fc2_w() + j * s.O + o] = d.fc2_w[i];
-    }
-    for (int i = tid; i < s.O; i += blockDim.x) lds[s.fc2_b() + i] = d.fc2_b[i];
-    float* xs = lds + s.per_wave() + wave * s.wave_floats();
-    float* ys = xs + s.C * s.P;
-    float* hs = ys + RP;
+    const int RP = s.RP();
+    stage_copy(lds + s.conv_w(), d.conv_w, s.R * s.C, tid);
+    stage_copy(lds + s.conv_b(), d.conv_b, s.R, tid);
+    stage_copy(lds + s.fc1_w(), d.fc1_w, s.Hd * RP, tid);
+    stage_copy(lds + s.fc1_b(), d.fc1_b, s.Hd, tid);
+    stage_copy(lds + s.fc2_w(), d.fc2_w, s.O * s.Hd, tid);
+    stage_copy(lds + s.fc2_b(), d.fc2_b, s.O, tid);
     const int CP = s.C * s.P;
+    float* xs = lds + s.per_wave() + wave * s.wave_floats();
+    float* ys = xs + CP;
+    float* part = ys + RP;
+    float* hs = part + s.split * s.Hd;
     // every wave runs the same number of rounds (the barriers are workgroup-wide); a wave without a sample idles
     for (int first = blockIdx.x * kHeadWaves; first < batch; first += gridDim.x * kHeadWaves) {
         const int b = first + wave;
@@ -141,6 +160,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
         if (live) {
             const float* src = x + static_cast<size_t>(b) * CP;
             if ((CP & 3) == 0) {
+#pragma unroll 4
                 for (int i = lane; i < CP / 4; i += 64)
                     reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(src)[i];
             } else {
@@ -149,20 +169,50 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
         }
         __syncthreads();
         if (live) {
-            for (int idx = lane; idx < RP; idx += 64) {  // 1x1 convolution: y[r][p] = b[r] + sum_c w[r][c] x[c][p]
+            for (int idx = lane; idx < RP; idx += 64) {  // 1x1 convolution: y[r][p] = sum_c w[r][c] x[c][p] + b[r]
                 const int r = idx / s.P, p = idx - r * s.P;
                 const float* w = lds + s.conv_w() + r * s.C;
                 float acc = 0.f;
+#pragma unroll 8
                 for (int c = 0; c < s.C; ++c) acc += w[c] * xs[c * s.P + p];
                 ys[idx] = acc + lds[s.conv_b() + r];
             }
         }
         __syncthreads();
-        if (live) {
-            for (int j = lane; j < s.Hd; j += 64) {  // Linear + ELU
-                const float* w = lds + s.fc1_w() + j;
+        if (live) {  // Linear: hidden unit j; its columns g, g + split, ... per lane, or all of them from column j on
+            const int g = lane / s.Hd, j = lane - g * s.Hd;
+            if (g < s.split) {
+                const float* w = lds + s.fc1_w() + j * RP;
                 float acc = 0.f;
-                for (int k = 0; k < RP; ++k) acc += w[k * s.Hd] * ys[k];
+                if (s.split > 1) {
+#pragma unroll 8
+                    for (int k = g; k < RP; k += s.split) acc += w[k] * ys[k];
+                } else {
+                    int k = j % RP;
+#pragma unroll 8
+                    for (int t = 0; t < RP; ++t) {
+                        acc += w[k] * ys[k];
+                        k = (k + 1 == RP) ? 0 : k + 1;
+                    }
+                }
+                part[g * s.Hd + j] = acc;
+            }
+            for (int jj = lane + 64; jj < s.Hd; jj += 64) {  // hidden layers wider than the wave (split == 1)
+                const float* w = lds + s.fc1_w() + jj * RP;
+                float acc = 0.f;
+                int k = jj % RP;
+                for (int t = 0; t < RP; ++t) {
+                    acc += w[k] * ys[k];
+                    k = (k + 1 == RP) ? 0 : k + 1;
+                }
+                part[jj] = acc;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int j = lane; j < s.Hd; j += 64) {  // partial sums in order, bias, ELU
+                float acc = part[j];
+                for (int g = 1; g < s.split; ++g) acc += part[g * s.Hd + j];
                 acc += lds[s.fc1_b() + j];
                 hs[j] = acc > 0.f ? acc : expf(acc) - 1.f;
             }
@@ -170,9 +220,14 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
         __syncthreads();
         if (live) {
             for (int o = lane; o < s.O; o += 64) {  // Linear
-                const float* w = lds + s.fc2_w() + o;
+                const float* w = lds + s.fc2_w() + o * s.Hd;
                 float acc = 0.f;
-                for (int j = 0; j < s.Hd; ++j) acc += w[j * s.O] * hs[j];
+                int j = o % s.Hd;
+#pragma unroll 8
+                for (int t = 0; t < s.Hd; ++t) {
+                    acc += w[j] * hs[j];
+                    j = (j + 1 == s.Hd) ? 0 : j + 1;
+                }
                 out[static_cast<size_t>(b) * s.O + o] = acc + lds[s.fc2_b() + o];
             }
         }
@@ -201,7 +256,9 @@ extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float
     if (!x || !d || !out || !d->conv_w || !d->conv_b || !d->fc1_w || !d->fc1_b || !d->fc2_w || !d->fc2_b || batch < 0 ||
         batch > 0x7fffffff || d->channels <= 0 || d->plane <= 0 || d->reduced <= 0 || d->hidden <= 0 || d->outputs <= 0)
         return MZMCTS_ERR_INVALID;
-    const mz::HeadShape s{d->channels, d->plane, d->reduced, d->hidden, d->outputs};
+    int split = 1;
+    while (split * 2 * d->hidden <= 64) split *= 2;  // lanes per hidden unit (a power of two; 1 from 33 units on)
+    const mz::HeadShape s{d->channels, d->plane, d->reduced, d->hidden, d->outputs, split};
     const size_t lds = sizeof(float) * static_cast<size_t>(s.total());
     if (lds > 160 * 1024 || (reinterpret_cast<uintptr_t>(x) & 15u)) return MZMCTS_ERR_INVALID;  // caller falls back
     if (batch == 0) return MZMCTS_OK;
