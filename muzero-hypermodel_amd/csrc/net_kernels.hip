@@ -118,6 +118,14 @@ struct HeadShape {
     __host__ __device__ int total() const { return per_wave() + kHeadWaves * wave_floats(); }
 };
 
+// Orders this wave's LDS writes before its following LDS reads (other lanes' data), for the compiler and the
+// memory counters; no other wave is involved.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // dst[0..n) = src[0..n) by the whole workgroup, eight independent loads per thread in flight
 __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n, int tid) {
     constexpr int kInFlight = 8, kThreads = 64 * kHeadWaves;
@@ -152,22 +160,24 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
     float* ys = xs + CP;
     float* part = ys + RP;
     float* hs = part + s.split * s.Hd;
-    // every wave runs the same number of rounds (the barriers are workgroup-wide); a wave without a sample idles
-    for (int first = blockIdx.x * kHeadWaves; first < batch; first += gridDim.x * kHeadWaves) {
-        const int b = first + wave;
-        const bool live = b < batch;
-        __syncthreads();  // weights staged / the previous round's buffers are free
-        if (live) {
-            const float* src = x + static_cast<size_t>(b) * CP;
-            if ((CP & 3) == 0) {
+    // The sample buffers belong to the wave: between its steps it needs its own LDS writes to have landed (LDS serves
+    // a wave's accesses in order), not a workgroup barrier.  The one barrier is for the staged weights.
+    auto load_board = [&](int b) {
+        const float* src = x + static_cast<size_t>(b) * CP;
+        if ((CP & 3) == 0) {
 #pragma unroll 4
-                for (int i = lane; i < CP / 4; i += 64)
-                    reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(src)[i];
-            } else {
-                for (int i = lane; i < CP; i += 64) xs[i] = src[i];
-            }
+            for (int i = lane; i < CP / 4; i += 64) reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(src)[i];
+        } else {
+            for (int i = lane; i < CP; i += 64) xs[i] = src[i];
         }
-        __syncthreads();
+    };
+    int b = blockIdx.x * kHeadWaves + wave;
+    if (b < batch) load_board(b);  // in flight together with the weights
+    __syncthreads();               // the staged weights, for every wave (also the ones without a sample)
+    for (bool first = true; b < batch; b += gridDim.x * kHeadWaves, first = false) {
+        const bool live = true;
+        if (!first) load_board(b);
+        wave_sync();
         if (live) {
             for (int idx = lane; idx < RP; idx += 64) {  // 1x1 convolution: y[r][p] = sum_c w[r][c] x[c][p] + b[r]
                 const int r = idx / s.P, p = idx - r * s.P;
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
                 ys[idx] = acc + lds[s.conv_b() + r];
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {  // Linear: hidden unit j; its columns g, g + split, ... per lane, or all of them from column j on
             const int g = lane / s.Hd, j = lane - g * s.Hd;
             if (g < s.split) {
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
                 part[jj] = acc;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             for (int j = lane; j < s.Hd; j += 64) {  // partial sums in order, bias, ELU
                 float acc = part[j];
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
                 hs[j] = acc > 0.f ? acc : expf(acc) - 1.f;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {
             for (int o = lane; o < s.O; o += 64) {  // Linear
                 const float* w = lds + s.fc2_w() + o * s.Hd;
