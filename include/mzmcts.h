@@ -297,6 +297,13 @@ int mzmcts_moves_ring(mzmcts_engine *engine, void **host_base, int64_t *move_str
 int mzmcts_affine_act(const float *x, const float *scale, const float *shift, const float *residual, float *out,
                       int64_t count, int32_t channels, int32_t plane, int32_t relu, void *stream);
 
+/* The dynamics network's input (models.py:553-568): out[b] = state[b]'s `channels` planes followed by one plane
+ * filled with action[b] / action_space.  state dev f32[batch, channels, plane], action dev i64[batch],
+ * out dev f32[batch, channels + 1, plane]; batch <= 65535.  One launch for torch's cast, division and cat;
+ * the same fp32 division, so bit-identical. */
+int mzmcts_state_action_planes(const float *state, const int64_t *action, float *out, int64_t batch,
+                               int32_t channels, int32_t plane, int32_t action_space, void *stream);
+
 /* The hidden-state rescale of the residual networks (models.py:525-549, 586-602): every row of `row_len`
  * floats (one (sample, channel) board plane) becomes (x - min) / span, span = max - min (+ 1e-5 when below
  * 1e-5).  x, out: dev f32[rows, row_len] contiguous, out may be x.  row_len <= 128.  One launch instead of

@@ -100,6 +100,8 @@ PROTOTYPES = {
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_get_profile": (ctypes.c_int, [c_void, ctypes.POINTER(MzProfile), ctypes.c_int32]),
     "mzmcts_device_bytes": (ctypes.c_int64, [c_void]),
+    "mzmcts_state_action_planes": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_int32, c_void]),
     "mzmcts_conv_head": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "mzmcts_unit_rescale": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int32, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),

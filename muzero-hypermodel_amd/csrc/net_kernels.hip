@@ -244,7 +244,36 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
     }
 }
 
+// The dynamics network's input (reference models.py:553-568): the hidden state's planes followed by one plane
+// holding action / action_space_size -- through torch a cast, a division, an expand and a concatenation.
+__global__ __launch_bounds__(256) void state_action_planes_kernel(const float* __restrict__ state,
+                                                                  const int64_t* __restrict__ action,
+                                                                  float* __restrict__ out, uint32_t state_floats,
+                                                                  uint32_t plane, float action_space) {
+    const uint32_t b = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= state_floats + plane) return;
+    const size_t o = static_cast<size_t>(b) * (state_floats + plane) + i;
+    if (i < state_floats)
+        out[o] = state[static_cast<size_t>(b) * state_floats + i];
+    else
+        out[o] = static_cast<float>(action[b]) / action_space;
+}
+
 }  // namespace mz
+
+extern "C" int mzmcts_state_action_planes(const float* state, const int64_t* action, float* out, int64_t batch,
+                                          int32_t channels, int32_t plane, int32_t action_space, void* stream_) {
+    if (!state || !action || !out || batch < 0 || batch > 65535 || channels <= 0 || plane <= 0 || action_space <= 0 ||
+        static_cast<int64_t>(channels + 1) * plane > 0x7fffffff)
+        return MZMCTS_ERR_INVALID;
+    if (batch == 0) return MZMCTS_OK;
+    const uint32_t state_floats = static_cast<uint32_t>(channels) * static_cast<uint32_t>(plane);
+    const dim3 grid((state_floats + static_cast<uint32_t>(plane) + 255u) / 256u, static_cast<unsigned>(batch));
+    mz::state_action_planes_kernel<<<grid, dim3(256), 0, static_cast<hipStream_t>(stream_)>>>(
+        state, action, out, state_floats, static_cast<uint32_t>(plane), static_cast<float>(action_space));
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
 
 extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int32_t row_len, void* stream_) {
     if (!x || !out || rows < 0 || rows > 0x7fffffff || row_len <= 0 || row_len > 128) return MZMCTS_ERR_INVALID;

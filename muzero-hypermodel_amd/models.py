@@ -111,6 +111,26 @@ def board_rescale(raw, out=None):
     return out
 
 
+def state_action_planes(state, action, action_space_size):
+    """The dynamics input: the hidden state's planes plus one plane of action / action_space_size (reference
+    models.py:553-568).  Inference on the GPU with an int64 [B, 1] action batch (what select hands over): one HIP
+    launch (include/mzmcts.h mzmcts_state_action_planes), bit-identical to the torch expression below."""
+    b, c, h, w = state.shape
+    native = (state.is_cuda and state.dtype == torch.float32 and action.dtype == torch.int64 and action.is_cuda
+              and action.numel() == b and b <= 65535 and not (torch.is_grad_enabled() and state.requires_grad))
+    if not native:
+        plane = (action.to(state.dtype) / action_space_size)[:, :, None, None]
+        return torch.cat((state, plane.expand(b, 1, h, w)), dim=1)
+    state, action = state.contiguous(), action.contiguous()
+    out = torch.empty((b, c + 1, h, w), dtype=torch.float32, device=state.device)
+    with torch.cuda.device(state.device):
+        rc = _native.load().mzmcts_state_action_planes(state.data_ptr(), action.data_ptr(), out.data_ptr(), b, c, h * w,
+                                                       action_space_size, torch.cuda.current_stream(state.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"mzmcts_state_action_planes failed ({rc}) on a tensor of shape {tuple(state.shape)}")
+    return out
+
+
 class AbstractNetwork(torch.nn.Module):
     """reference models.py:56-73"""
 
@@ -463,9 +483,7 @@ class MuZeroResidualNetwork(AbstractNetwork):
         return board_rescale(self.representation_network(observation))
 
     def dynamics(self, encoded_state, action, out_state=None):
-        b, _, h, w = encoded_state.shape
-        plane = (action.to(encoded_state.dtype) / self.action_space_size)[:, :, None, None]
-        x = torch.cat((encoded_state, plane.expand(b, 1, h, w)), dim=1)
+        x = state_action_planes(encoded_state, action, self.action_space_size)
         raw, reward = self.dynamics_network(x)
         return board_rescale(raw, out=out_state), reward
 
