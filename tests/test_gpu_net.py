@@ -128,3 +128,30 @@ def test_state_action_planes_equal_torch_expression(pkg, batch, channels, board,
     assert torch.allclose(got, on_gpu, rtol=2e-7, atol=0)
     live = state.clone().requires_grad_(True)          # with autograd: the torch expression
     assert models.state_action_planes(live, action, actions).requires_grad
+
+
+def test_board_convolution_as_one_gemm(pkg):
+    """models.BoardConv2d: on small boards the padded 3x3 convolution (reference models.py:199-203 conv3x3) runs as
+    one GEMM over the expanded weight matrix; equal to the convolution to fp32 rounding, follows in-place weight
+    updates (version counter) and updates behind its back (refold), larger boards keep the MIOpen path."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    torch.manual_seed(4)
+    conv = models.conv3x3(17, 16).cuda().eval()
+    x = torch.randn(4096, 17, 3, 3, device="cuda")
+    with torch.no_grad():
+        for step in range(3):
+            got = conv(x)
+            want = torch.nn.functional.conv2d(x.cpu(), conv.weight.cpu(), padding=1)
+            assert got.shape == (4096, 16, 3, 3)
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+            matrix = conv.dense(3, 3)
+            if step == 0:
+                conv.weight.mul_(0.5)                                   # in place: the version counter moves
+            else:
+                conv.weight.data.add_(0.25)                              # behind its back ...
+                conv.refold()                                            # ... signalled, as after a broadcast
+            assert conv.dense(3, 3).data_ptr() == matrix.data_ptr()      # refreshed in place (hipGraph replays)
+        big = torch.randn(8, 17, 6, 7, device="cuda")                    # 42 positions: MIOpen
+        assert torch.allclose(conv(big), torch.nn.functional.conv2d(big, conv.weight, padding=1), rtol=1e-4, atol=1e-4)
+    conv.train()
+    assert conv(x[:4].requires_grad_(True)).requires_grad               # training / autograd: torch's convolution
