@@ -175,10 +175,9 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
     if (b < batch) load_board(b);  // in flight together with the weights
     __syncthreads();               // the staged weights, for every wave (also the ones without a sample)
     for (bool first = true; b < batch; b += gridDim.x * kHeadWaves, first = false) {
-        const bool live = true;
         if (!first) load_board(b);
         wave_sync();
-        if (live) {
+        {
             for (int idx = lane; idx < RP; idx += 64) {  // 1x1 convolution: y[r][p] = sum_c w[r][c] x[c][p] + b[r]
                 const int r = idx / s.P, p = idx - r * s.P;
                 const float* w = lds + s.conv_w() + r * s.C;
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
             }
         }
         wave_sync();
-        if (live) {  // Linear: hidden unit j; its columns g, g + split, ... per lane, or all of them from column j on
+        {  // Linear: hidden unit j; its columns g, g + split, ... per lane, or all of them from column j on
             const int g = lane / s.Hd, j = lane - g * s.Hd;
             if (g < s.split) {
                 const float* w = lds + s.fc1_w() + j * RP;
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
             }
         }
         wave_sync();
-        if (live) {
+        {
             for (int j = lane; j < s.Hd; j += 64) {  // partial sums in order, bias, ELU
                 float acc = part[j];
                 for (int g = 1; g < s.split; ++g) acc += part[g * s.Hd + j];
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float*
             }
         }
         wave_sync();
-        if (live) {
+        {
             for (int o = lane; o < s.O; o += 64) {  // Linear
                 const float* w = lds + s.fc2_w() + o * s.Hd;
                 float acc = 0.f;
