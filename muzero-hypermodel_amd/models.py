@@ -360,13 +360,26 @@ class BoardConv2d(torch.nn.Conv2d):
         return (self.weight._version, self.weight.data_ptr(), self.weight.device)
 
     def refold(self):
-        """Rebuild every cached expanded matrix from the current weight, in place."""
+        """Rebuild every cached expanded matrix from the current weight (and the batch norms folded into some of
+        them), in place."""
         with torch.no_grad():
             for (h, w, _), matrix in self.__dict__.get("_dense", {}).items():
                 index, mask = self._expansion(h, w, self.weight.device)
                 matrix.copy_(torch.take(self.weight, index))
                 matrix.mul_(mask)
+            for (h, w, _, _), (matrix, bias, bn) in self.__dict__.get("_dense_bn", {}).items():
+                bn.refold()  # (explicitly: a broadcast into aliased storage moves no version counter)
+                scale, shift = bn.folded()
+                torch.mul(self.dense_matrix(h, w), scale.repeat_interleave(h * w)[None, :], out=matrix)
+                bias.copy_(shift.repeat_interleave(h * w))
         self._dense_version = self._dense_key()
+        self._dense_bn_version = self._dense_bn_key()
+
+    def _dense_bn_key(self):
+        return tuple(bn._fold_key() for (_, _, bn) in self.__dict__.get("_dense_bn", {}).values())
+
+    def dense_matrix(self, h, w):
+        return self.__dict__["_dense"][(h, w, str(self.weight.device))]
 
     def dense(self, h, w):
         cache = self.__dict__.setdefault("_dense", {})
@@ -379,15 +392,41 @@ class BoardConv2d(torch.nn.Conv2d):
             self.refold()
         return cache[key]
 
-    def forward(self, x):
+    def dense_with(self, bn, h, w):
+        """(expanded matrix with `bn`'s eval-mode scale folded into its columns, bias row): relu(x @ m + bias) is
+        relu(bn(conv(x))) in one GEMM with a fused epilogue."""
+        self.dense(h, w)
+        cache = self.__dict__.setdefault("_dense_bn", {})
+        key = (h, w, str(self.weight.device), id(bn))
+        if key not in cache:
+            matrix = torch.empty_like(self.dense_matrix(h, w))
+            cache[key] = (matrix, torch.empty(matrix.shape[1], dtype=matrix.dtype, device=matrix.device), bn)
+            self._dense_bn_version = None
+        if getattr(self, "_dense_bn_version", None) != self._dense_bn_key() or self._dense_version != self._dense_key():
+            self.refold()
+        return cache[key][:2]
+
+    def takes_dense_path(self, x):
         h, w = x.shape[2], x.shape[3]
-        dense = (not self.training and x.is_cuda and x.dtype == torch.float32
-                 and self.in_channels * self.out_channels * (h * w) ** 2 <= self.DENSE_MAX_ELEMENTS
-                 and self.stride == (1, 1) and not torch.is_grad_enabled())
-        if not dense:
+        return (not self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and self.in_channels * self.out_channels * (h * w) ** 2 <= self.DENSE_MAX_ELEMENTS
+                and self.stride == (1, 1) and not torch.is_grad_enabled())
+
+    def forward(self, x):
+        if not self.takes_dense_path(x):
             return super().forward(x)
-        b = x.shape[0]
+        b, _, h, w = x.shape
         return torch.mm(x.reshape(b, -1), self.dense(h, w)).view(b, self.out_channels, h, w)
+
+
+def conv_bn_relu(conv, bn, x):
+    """relu(bn(conv(x))) (reference models.py:215-225, 318-330).  On the dense small-board path in inference: ONE
+    GEMM -- batch-norm scale folded into the expanded matrix, shift and ReLU in the GEMM's epilogue."""
+    if isinstance(conv, BoardConv2d) and conv.takes_dense_path(x) and not bn.training:
+        b, _, h, w = x.shape
+        matrix, bias = conv.dense_with(bn, h, w)
+        return torch._addmm_activation(bias, x.reshape(b, -1), matrix).view(b, conv.out_channels, h, w)
+    return conv_epilogue(conv(x), bn)
 
 
 def conv3x3(in_channels, out_channels, stride=1):
@@ -403,7 +442,7 @@ class ResidualBlock(torch.nn.Module):
         self.bn2 = BatchNorm2d(num_channels)
 
     def forward(self, x):
-        y = conv_epilogue(self.conv1(x), self.bn1)
+        y = conv_bn_relu(self.conv1, self.bn1, x)
         return conv_epilogue(self.conv2(y), self.bn2, residual=x)
 
 
@@ -475,7 +514,7 @@ class RepresentationNetwork(torch.nn.Module):
         self.resblocks = _tower(num_channels, num_blocks)
 
     def forward(self, x):
-        x = self.downsample_net(x) if self.downsample else conv_epilogue(self.conv(x), self.bn)
+        x = self.downsample_net(x) if self.downsample else conv_bn_relu(self.conv, self.bn, x)
         for block in self.resblocks:
             x = block(x)
         return x
@@ -493,7 +532,7 @@ class DynamicsNetwork(torch.nn.Module):
         self.fc = mlp(block_output_size_reward, fc_reward_layers, full_support_size)
 
     def forward(self, x):
-        x = conv_epilogue(self.conv(x), self.bn)
+        x = conv_bn_relu(self.conv, self.bn, x)
         for block in self.resblocks:
             x = block(x)
         reward = conv_head(x, self.conv1x1_reward, self.fc, self.block_output_size_reward)

@@ -195,3 +195,31 @@ def test_resnet_graph_replay_follows_a_weight_refresh(pkg):
     eager.close()
     assert not np.array_equal(before[1], after[1])
     assert np.array_equal(after[0], want[0]) and np.array_equal(after[1], want[1])
+
+
+def test_board_convolution_with_folded_batch_norm(pkg):
+    """models.conv_bn_relu on the dense path: relu(bn(conv(x))) as one GEMM with the batch norm folded in; equal to
+    the unfused expression to fp32 rounding, before and after the parameters change (in place, and behind the
+    modules' backs followed by refresh_inference_constants-style refolds in module order: convolution first)."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    torch.manual_seed(9)
+    conv, bn = models.conv3x3(16, 16).cuda().eval(), models.BatchNorm2d(16).cuda().eval()
+    x = torch.randn(512, 16, 3, 3, device="cuda")
+    with torch.no_grad():
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.running_mean.normal_()
+        for step in range(3):
+            got = models.conv_bn_relu(conv, bn, x)
+            want = torch.relu(torch.nn.functional.batch_norm(
+                torch.nn.functional.conv2d(x.cpu(), conv.weight.cpu(), padding=1), bn.running_mean.cpu(),
+                bn.running_var.cpu(), bn.weight.cpu(), bn.bias.cpu(), False, 0.0, bn.eps))
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+            if step == 0:
+                bn.weight.mul_(1.5)                      # version counters move
+                conv.weight.add_(0.1)
+            else:
+                bn.bias.data.add_(0.3)                   # behind their backs ...
+                bn.running_mean.data.sub_(0.2)
+                conv.weight.data.mul_(0.7)
+                conv.refold()                            # ... refreshed in module order, convolution first
+                bn.refold()
