@@ -322,6 +322,10 @@ typedef struct mzmcts_head_desc {
     int32_t channels, plane, reduced, hidden, outputs;
 } mzmcts_head_desc;
 int mzmcts_conv_head(const float *x, const mzmcts_head_desc *head, float *out, int64_t batch, void *stream);
+/* n_heads (1 or 2) heads reading the same x in one launch (value and policy, models.py:500-522): heads[h] writes
+ * outs[h] dev f32[batch, heads[h].outputs]; all heads share channels and plane. */
+int mzmcts_conv_heads(const float *x, const mzmcts_head_desc *heads, int32_t n_heads, float *const *outs,
+                      int64_t batch, void *stream);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);

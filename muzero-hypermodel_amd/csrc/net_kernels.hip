@@ -144,8 +144,18 @@ __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float* __restrict__ x, mzmcts_head_desc d,
-                                                                     HeadShape s, float* __restrict__ out, int batch) {
+// Up to two heads that read the same board (value and policy) share a launch: blockIdx.y picks the head.
+constexpr int kMaxHeads = 2;
+struct HeadSet {
+    mzmcts_head_desc desc[kMaxHeads];
+    HeadShape shape[kMaxHeads];
+    float* out[kMaxHeads];
+};
+
+__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float* __restrict__ x, HeadSet set, int batch) {
+    const mzmcts_head_desc d = set.desc[blockIdx.y];
+    const HeadShape s = set.shape[blockIdx.y];
+    float* __restrict__ out = set.out[blockIdx.y];
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int RP = s.RP();
@@ -290,15 +300,27 @@ extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
-extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float* out, int64_t batch, void* stream_) {
-    if (!x || !d || !out || !d->conv_w || !d->conv_b || !d->fc1_w || !d->fc1_b || !d->fc2_w || !d->fc2_b || batch < 0 ||
-        batch > 0x7fffffff || d->channels <= 0 || d->plane <= 0 || d->reduced <= 0 || d->hidden <= 0 || d->outputs <= 0)
+extern "C" int mzmcts_conv_heads(const float* x, const mzmcts_head_desc* heads, int32_t n_heads, float* const* outs,
+                                 int64_t batch, void* stream_) {
+    if (!x || !heads || !outs || n_heads < 1 || n_heads > mz::kMaxHeads || batch < 0 || batch > 0x7fffffff ||
+        (reinterpret_cast<uintptr_t>(x) & 15u))
         return MZMCTS_ERR_INVALID;
-    int split = 1;
-    while (split * 2 * d->hidden <= 64) split *= 2;  // lanes per hidden unit (a power of two; 1 from 33 units on)
-    const mz::HeadShape s{d->channels, d->plane, d->reduced, d->hidden, d->outputs, split};
-    const size_t lds = sizeof(float) * static_cast<size_t>(s.total());
-    if (lds > 160 * 1024 || (reinterpret_cast<uintptr_t>(x) & 15u)) return MZMCTS_ERR_INVALID;  // caller falls back
+    mz::HeadSet set{};
+    size_t lds = 0;
+    for (int h = 0; h < n_heads; ++h) {
+        const mzmcts_head_desc* d = heads + h;
+        if (!outs[h] || !d->conv_w || !d->conv_b || !d->fc1_w || !d->fc1_b || !d->fc2_w || !d->fc2_b || d->channels <= 0 ||
+            d->plane <= 0 || d->reduced <= 0 || d->hidden <= 0 || d->outputs <= 0 || d->channels != heads[0].channels ||
+            d->plane != heads[0].plane)
+            return MZMCTS_ERR_INVALID;
+        int split = 1;
+        while (split * 2 * d->hidden <= 64) split *= 2;  // lanes per hidden unit (a power of two; 1 from 33 units on)
+        set.desc[h] = *d;
+        set.shape[h] = mz::HeadShape{d->channels, d->plane, d->reduced, d->hidden, d->outputs, split};
+        set.out[h] = outs[h];
+        lds = std::max(lds, sizeof(float) * static_cast<size_t>(set.shape[h].total()));
+    }
+    if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;  // the caller keeps the torch modules
     if (batch == 0) return MZMCTS_OK;
     if (lds > 64 * 1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(mz::conv_head_kernel),
@@ -307,10 +329,15 @@ extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float
     }
     const int64_t rounds = (batch + mz::kHeadWaves - 1) / mz::kHeadWaves;
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
-    const dim3 grid(static_cast<unsigned>(std::min<int64_t>(rounds, 256 * per_cu)));
-    mz::conv_head_kernel<<<grid, dim3(64 * mz::kHeadWaves), lds, static_cast<hipStream_t>(stream_)>>>(
-        x, *d, s, out, static_cast<int>(batch));
+    const dim3 grid(static_cast<unsigned>(std::min<int64_t>(rounds, 256 * per_cu)), static_cast<unsigned>(n_heads));
+    mz::conv_head_kernel<<<grid, dim3(64 * mz::kHeadWaves), lds, static_cast<hipStream_t>(stream_)>>>(x, set,
+                                                                                                    static_cast<int>(batch));
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float* out, int64_t batch, void* stream) {
+    float* outs[1] = {out};
+    return mzmcts_conv_heads(x, d, 1, outs, batch, stream);
 }
 
 extern "C" int mzmcts_affine_act(const float* x, const float* scale, const float* shift, const float* residual, float* out,

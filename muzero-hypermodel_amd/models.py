@@ -296,30 +296,40 @@ class PointwiseConv2d(torch.nn.Conv2d):
         return out.view(b, h, w, self.out_channels).permute(0, 3, 1, 2)
 
 
-def conv_head(x, conv, fc, flat_size):
-    """fc(conv(x).reshape(-1, flat_size)): a reward / value / policy head (reference models.py:467-480, 500-522).
-    Inference on the GPU with the usual one-hidden-layer MLP: one HIP launch (include/mzmcts.h mzmcts_conv_head)
-    reading the modules' own parameters; anything else (training, autograd, CPU, deeper MLPs, heads too large
-    for LDS) evaluates the torch modules."""
-    native = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled()
-              and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and isinstance(fc[1], torch.nn.ELU)
-              and fc[1].alpha == 1.0 and isinstance(fc[2], torch.nn.Linear) and isinstance(fc[3], torch.nn.Identity)
-              and conv.bias is not None)
-    if native:
+def _head_is_native(x, conv, fc):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled()
+            and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and isinstance(fc[1], torch.nn.ELU)
+            and fc[1].alpha == 1.0 and isinstance(fc[2], torch.nn.Linear) and isinstance(fc[3], torch.nn.Identity)
+            and conv.bias is not None)
+
+
+def conv_heads(x, heads):
+    """[fc(conv(x).reshape(-1, flat_size)) for (conv, fc, flat_size) in heads]: reward / value / policy heads that
+    read the same tensor (reference models.py:467-480, 500-522).  Inference on the GPU with the usual
+    one-hidden-layer MLPs: ONE HIP launch for up to two heads (include/mzmcts.h mzmcts_conv_heads) reading the
+    modules' own parameters; anything else (training, autograd, CPU, deeper MLPs, heads too large for LDS)
+    evaluates the torch modules."""
+    if 1 <= len(heads) <= 2 and all(_head_is_native(x, conv, fc) for conv, fc, _ in heads):
         x = x.contiguous()
         b, c, h, w = x.shape
-        desc = _native.MzHeadDesc(conv.weight.data_ptr(), conv.bias.data_ptr(), fc[0].weight.data_ptr(),
-                                  fc[0].bias.data_ptr(), fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), c, h * w,
-                                  conv.out_channels, fc[0].out_features, fc[2].out_features)
-        out = torch.empty((b, fc[2].out_features), dtype=torch.float32, device=x.device)
+        descs = (_native.MzHeadDesc * len(heads))(*[
+            _native.MzHeadDesc(conv.weight.data_ptr(), conv.bias.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
+                               fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), c, h * w, conv.out_channels,
+                               fc[0].out_features, fc[2].out_features) for conv, fc, _ in heads])
+        outs = [torch.empty((b, fc[2].out_features), dtype=torch.float32, device=x.device) for _, fc, _ in heads]
+        pointers = (ctypes.c_void_p * len(heads))(*[o.data_ptr() for o in outs])
         with torch.cuda.device(x.device):
-            rc = _native.load().mzmcts_conv_head(x.data_ptr(), ctypes.addressof(desc), out.data_ptr(), b,
-                                                 torch.cuda.current_stream(x.device).cuda_stream)
+            rc = _native.load().mzmcts_conv_heads(x.data_ptr(), ctypes.addressof(descs), len(heads), ctypes.addressof(pointers),
+                                                  b, torch.cuda.current_stream(x.device).cuda_stream)
         if rc == 0:
-            return out
-        if rc != -1:                                   # -1: the head does not fit in LDS -> torch modules
-            raise RuntimeError(f"mzmcts_conv_head failed ({rc}) on a tensor of shape {tuple(x.shape)}")
-    return fc(conv(x).reshape(-1, flat_size))
+            return outs
+        if rc != -1:                                   # -1: a head does not fit in LDS -> torch modules
+            raise RuntimeError(f"mzmcts_conv_heads failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+    return [fc(conv(x).reshape(-1, flat_size)) for conv, fc, flat_size in heads]
+
+
+def conv_head(x, conv, fc, flat_size):
+    return conv_heads(x, [(conv, fc, flat_size)])[0]
 
 
 class BoardConv2d(torch.nn.Conv2d):
@@ -555,8 +565,8 @@ class PredictionNetwork(torch.nn.Module):
     def forward(self, x):
         for block in self.resblocks:
             x = block(x)
-        value = conv_head(x, self.conv1x1_value, self.fc_value, self.block_output_size_value)
-        policy = conv_head(x, self.conv1x1_policy, self.fc_policy, self.block_output_size_policy)
+        value, policy = conv_heads(x, [(self.conv1x1_value, self.fc_value, self.block_output_size_value),
+                                       (self.conv1x1_policy, self.fc_policy, self.block_output_size_policy)])
         return policy, value
 
 

@@ -103,6 +103,14 @@ def test_conv_head_equals_torch_modules(pkg, batch, channels, board, reduced, hi
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
             fc[2].bias.add_(0.5)                       # second pass: refreshed weights, same storage
             conv.weight.mul_(-1.5)
+    other_conv = models.PointwiseConv2d(channels, max(1, reduced // 2)).cuda()
+    other_flat = other_conv.out_channels * board[0] * board[1]
+    other_fc = models.mlp(other_flat, [hidden + 3], outputs + 2).cuda()
+    with torch.no_grad():                                             # two heads on the same board: one launch
+        a, b2 = models.conv_heads(x, [(conv, fc, flat), (other_conv, other_fc, other_flat)])
+        np.testing.assert_allclose(a.cpu().numpy(), fc(conv(x).reshape(-1, flat)).cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(b2.cpu().numpy(), other_fc(other_conv(x).reshape(-1, other_flat)).cpu().numpy(),
+                                   rtol=1e-5, atol=1e-5)
     assert models.conv_head(x, conv, fc, flat).requires_grad          # autograd on: the torch modules
     deep = models.mlp(flat, [hidden, hidden], outputs).cuda()         # two hidden layers: the torch modules
     with torch.no_grad():
