@@ -260,15 +260,18 @@ def conv_epilogue(x, bn, residual=None):
     the same order; training, autograd and CPU tensors take the torch expression."""
     native = (x.is_cuda and not bn.training and x.dtype == torch.float32 and x.dim() == 4
               and not (torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad))))
+    if native:
+        scale, shift = bn.folded()
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        # the kernel moves 16 bytes per lane: fresh torch allocations are aligned, odd views of them need not be
+        native = x.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0)
     if not native:
         y = bn(x)
         if residual is not None:
             y = y + residual
         return torch.relu(y)
-    scale, shift = bn.folded()
-    x = x.contiguous()
-    if residual is not None:
-        residual = residual.contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         rc = _native.load().mzmcts_affine_act(

@@ -231,3 +231,16 @@ def test_board_convolution_with_folded_batch_norm(pkg):
                 conv.weight.data.mul_(0.7)
                 conv.refold()                            # ... refreshed in module order, convolution first
                 bn.refold()
+
+
+def test_conv_epilogue_on_a_misaligned_view_takes_torch(pkg):
+    """A contiguous view that does not start on a 16-byte boundary (the kernel's access width) is evaluated by the
+    torch expression instead of failing."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    bn = models.BatchNorm2d(4).cuda().eval()
+    base = torch.randn(2 * 4 * 3 * 3 + 1, device="cuda")
+    x = base[1:].view(2, 4, 3, 3)
+    assert x.is_contiguous() and x.data_ptr() % 16 != 0
+    with torch.no_grad():
+        got = models.conv_epilogue(x, bn)
+        assert torch.equal(got, torch.relu(bn(x)))
