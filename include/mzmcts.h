@@ -141,6 +141,11 @@ int mzmcts_expand_roots_injected(mzmcts_engine *engine, const double *root_rewar
  * batch for recurrent_inference (self_play.py:339-343):
  *   parent_hidden_out dev f32[E,H] or NULL (skip the gather), action_out dev i64[E] or NULL */
 int mzmcts_select(mzmcts_engine *engine, float *parent_hidden_out, int64_t *action_out, void *stream);
+/* The same, with the gather laid out as the residual networks' dynamics input (models.py:553-568): row e of
+ * planes_out = [parent hidden state, hidden_floats = channels x plane | one plane of action / action_space]:
+ *   planes_out dev f32[E, channels + 1, plane], action_out dev i64[E] (also written, as by mzmcts_select). */
+int mzmcts_select_planes(mzmcts_engine *engine, float *planes_out, int64_t *action_out, int32_t plane,
+                         int32_t action_space, void *stream);
 
 /* expand_backup: support_to_scalar on value/reward (self_play.py:344-345), node.expand over the
  * full action space (self_play.py:346-352, 452-466), backpropagate with MinMaxStats

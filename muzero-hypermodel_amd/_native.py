@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mzmcts_expand_roots": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
     "mzmcts_expand_roots_injected": (ctypes.c_int, [c_void, c_void, c_void, c_void]),
     "mzmcts_select": (ctypes.c_int, [c_void, c_void, c_void, c_void]),
+    "mzmcts_select_planes": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int32, ctypes.c_int32, c_void]),
     "mzmcts_expand_backup": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
     "mzmcts_expand_backup_injected": (ctypes.c_int, [c_void, c_void, c_void, c_void, c_void]),
     "mzmcts_hidden_slab": (c_void, [c_void, ctypes.c_int32]),

@@ -125,6 +125,20 @@ __global__ __launch_bounds__(256) void gather_hidden_kernel(TreeParams p, float*
     }
 }
 
+// The same gather laid out as the residual networks' dynamics input (reference models.py:553-568): row e =
+// [parent hidden state (H floats = channels x plane) | one plane filled with action / action_space_size].
+__global__ __launch_bounds__(256) void gather_dynamics_input_kernel(TreeParams p, const int64_t* __restrict__ action,
+                                                                    float* __restrict__ out, int plane,
+                                                                    float action_space) {
+    const int e = blockIdx.x;
+    const int k = p.leaf_parent[e];
+    const float* src = p.hidden + (static_cast<size_t>(k) * p.E + e) * p.H;
+    float* dst = out + static_cast<size_t>(e) * (p.H + plane);
+    const int row = p.H + plane;
+    const float fill = static_cast<float>(action[e]) / action_space;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < row; i += gridDim.y * blockDim.x) dst[i] = i < p.H ? src[i] : fill;
+}
+
 // Contiguous slab copy (network output -> pool slab) when the caller could not write in place.
 __global__ __launch_bounds__(256) void copy_slab_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -588,6 +602,15 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
         err = hipGetLastError();
     }
     return err;
+}
+
+hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
+                                        hipStream_t stream) {
+    int gy = (p.H + plane + 255) / 256;
+    if (gy > 8) gy = 8;
+    gather_dynamics_input_kernel<<<dim3(p.E, gy), dim3(256), 0, stream>>>(p, action, out, plane,
+                                                                           static_cast<float>(action_space));
+    return hipGetLastError();
 }
 
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,

@@ -48,6 +48,8 @@ hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const F
                                   const LaunchTiming* timing);
 hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
                          const LaunchTiming* timing);
+hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
+                                        hipStream_t stream);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
                                const float* policy_logits, const float* root_hidden, const double* inj_reward,
                                const double* inj_priors, const double* noise, const uint32_t* rng_skip,
@@ -700,6 +702,18 @@ int mzmcts_select(mzmcts_engine* eng, float* parent_hidden_out, int64_t* action_
     ProfScope scope(eng, stream, kProfSelect);
     MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream,
                                   scope.get()));
+    return MZMCTS_OK;
+}
+
+int mzmcts_select_planes(mzmcts_engine* eng, float* planes_out, int64_t* action_out, int32_t plane, int32_t action_space,
+                         void* stream_) {
+    if (!eng || !planes_out || !action_out) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select_planes: null argument");
+    if (plane <= 0 || action_space <= 0 || eng->p.H <= 0 || eng->p.H % plane != 0)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select_planes: hidden_floats must be channels x plane");
+    int rc = mzmcts_select(eng, nullptr, action_out, stream_);
+    if (rc) return rc;
+    MZ_HIP(eng, mz::launch_gather_dynamics_input(eng->p, action_out, planes_out, plane, action_space,
+                                                 static_cast<hipStream_t>(stream_)));
     return MZMCTS_OK;
 }
 

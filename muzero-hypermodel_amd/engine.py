@@ -201,6 +201,16 @@ class BatchedMCTS:
             self._h, self.batch_hidden.data_ptr() if gather and self.H else None,
             self.batch_action.data_ptr(), self._stream()))
 
+    def select_planes(self):
+        """select with the gather laid out as a residual network's dynamics input: [E, channels + 1, h, w], the last
+        plane action / A (reference models.py:553-568)."""
+        c, h, w = self.state_shape
+        if getattr(self, "batch_planes", None) is None:
+            self.batch_planes = torch.zeros((self.E, c + 1, h, w), dtype=torch.float32, device=self.device)
+        self._check(self._lib.mzmcts_select_planes(self._h, self.batch_planes.data_ptr(), self.batch_action.data_ptr(),
+                                                   h * w, self.A, self._stream()))
+        return self.batch_planes
+
     def expand_backup(self, value_logits, reward_logits, policy_logits, next_hidden=None):
         v, r, p = self._f32(value_logits, self.F), self._f32(reward_logits, self.F), self._f32(policy_logits, self.A)
         h = None if next_hidden is None else self._f32(next_hidden.reshape(self.E, -1), self.H)
@@ -255,10 +265,14 @@ class BatchedMCTS:
 
     # ---- the simulation loop ---------------------------------------------------------------------
     def _simulate_once(self, model):
-        self.select()
         slab = self.next_slab()
-        value, reward, policy, _ = model.recurrent_inference(
-            self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)
+        if len(self.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
+            # residual networks: the gather writes the dynamics input itself (state planes + action plane)
+            value, reward, policy, _ = model.recurrent_inference_from_planes(self.select_planes(), out_state=slab)
+        else:
+            self.select()
+            value, reward, policy, _ = model.recurrent_inference(
+                self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)
         self.expand_backup(value, reward, policy, None)
 
     def _run_simulations(self, model):

@@ -602,7 +602,10 @@ class MuZeroResidualNetwork(AbstractNetwork):
         return board_rescale(self.representation_network(observation))
 
     def dynamics(self, encoded_state, action, out_state=None):
-        x = state_action_planes(encoded_state, action, self.action_space_size)
+        return self.dynamics_from_planes(state_action_planes(encoded_state, action, self.action_space_size), out_state)
+
+    def dynamics_from_planes(self, x, out_state=None):
+        """dynamics on its ready-made input [B, channels + 1, h, w] (state planes + action / A plane)."""
         raw, reward = self.dynamics_network(x)
         return board_rescale(raw, out=out_state), reward
 
@@ -614,6 +617,13 @@ class MuZeroResidualNetwork(AbstractNetwork):
 
     def recurrent_inference(self, encoded_state, action, out_state=None):
         next_state, reward = self.dynamics(encoded_state, action, out_state)
+        policy_logits, value = self.prediction(next_state)
+        return value, reward, policy_logits, next_state
+
+    def recurrent_inference_from_planes(self, planes, out_state=None):
+        """recurrent_inference for a caller that already holds the dynamics input (the engine's gather writes it:
+        include/mzmcts.h mzmcts_select_planes)."""
+        next_state, reward = self.dynamics_from_planes(planes, out_state)
         policy_logits, value = self.prediction(next_state)
         return value, reward, policy_logits, next_state
 

@@ -244,3 +244,34 @@ def test_conv_epilogue_on_a_misaligned_view_takes_torch(pkg):
     with torch.no_grad():
         got = models.conv_epilogue(x, bn)
         assert torch.equal(got, torch.relu(bn(x)))
+
+
+def test_select_planes_lays_out_the_dynamics_input(pkg):
+    """include/mzmcts.h mzmcts_select_planes: the gather writes [parent hidden state | action / A plane] rows
+    (reference models.py:553-568).  At the first simulation every leaf's parent is the root, so the state planes must
+    be the root hidden states and the last plane the reported action over the action-space size (an fp32 division)."""
+    from parity_helpers import synthetic_model
+    eng = importlib.import_module("muzero-hypermodel_amd.engine")
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    E, A = 37, len(config.action_space)
+    model, _ = synthetic_model(models, config, "cuda")
+    rs = np.random.RandomState(2)
+    boards = rs.randint(0, 2, (E, 3, 3, 3)).astype(np.float32)
+    engine = eng.BatchedMCTS(config, E)
+    legal = [sorted(rs.choice(A, size=rs.randint(2, A + 1), replace=False).tolist()) for _ in range(E)]
+    with torch.no_grad():
+        value, reward, policy, hidden = model.initial_inference(torch.from_numpy(boards).cuda())
+        engine.begin_search(legal, [0] * E, True)
+        engine.expand_roots(value, reward.contiguous(), policy, hidden)
+        planes = engine.select_planes().clone()
+        actions = engine.batch_action.clone().view(E)
+    torch.cuda.synchronize()
+    c = config.channels
+    assert planes.shape == (E, c + 1, 3, 3)
+    assert torch.equal(planes[:, :c], hidden)
+    want = (actions.cpu().to(torch.float32) / A)[:, None, None].expand(E, 3, 3)
+    assert torch.equal(planes[:, c].cpu(), want)
+    for e in range(E):
+        assert int(actions[e]) in legal[e]
+    engine.close()
