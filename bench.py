@@ -132,6 +132,7 @@ def main():
             root values of a batch when it is done; kernels of one batch follow each other without host round
             trips.  trailing_predraw = (moves) draws one more batch during the last one (left uploaded-ready)."""
             trace = os.environ.get("MZ_BENCH_TRACE")
+            played = 0
             for n, (i, b) in enumerate(plan):
                 if world > 1 and args.bcast_every and i % args.bcast_every == 0:
                     actor.refresh_weights(src=0)
@@ -144,6 +145,7 @@ def main():
                     engine.moves_predraw_next(nxt, legal, to_play, temperature, True, num_legal=num_legal)
                 t.append(time.perf_counter())
                 out = engine.moves_collect(copy=bool(os.environ.get("MZ_BENCH_COPY")))   # default: views of the download ring
+                played += int(out["moves_done"].sum())   # an env whose stream left the pre-drawn path sits out the rest
                 t.append(time.perf_counter())
                 if n + 1 < len(plan):
                     engine.moves_submit_next()
@@ -152,6 +154,7 @@ def main():
                     print(f"[bench] batch of {b}: enqueue {1e3 * (t[1] - t[0]):.2f} ms, predraw {1e3 * (t[2] - t[1]):.2f}, "
                           f"collect {1e3 * (t[3] - t[2]):.2f}, submit {1e3 * (t[4] - t[3]):.2f}; moves done min "
                           f"{int(out['moves_done'].min())}", file=sys.stderr, flush=True)
+            return played
     elif fused and args.groups > 1:
         # n env groups on n streams: one group's host work overlaps the other groups' kernels
         n = args.groups
@@ -206,10 +209,11 @@ def main():
             engine.moves_submit_next()
         else:
             engine.moves_prepare(timed[0][1], legal, to_play, temperature, True, num_legal=num_legal)
-        run_plan(timed, timed[-1][1])
+        moves_played = run_plan(timed, timed[-1][1])
     else:
         for i in range(args.steps):
             one_step(i)
+        moves_played = E * args.steps
     if pipe:
         drain()                                          # every queued move is finished inside the timed region
     barrier()
@@ -220,7 +224,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    sims_total = world * E * S * args.steps
+    if world > 1:
+        t = torch.tensor([moves_played], dtype=torch.int64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        moves_played = int(t.item())
+    # only searches that really ran count: in move batches an env whose tie-break words differ from the pre-drawn
+    # assumption sits out the rest of its batch, so moves_played <= world * E * steps
+    sims_total = moves_played * S
     value = sims_total / elapsed
 
     result = {
@@ -239,7 +249,8 @@ def main():
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
                    "parallelism": f"actors{world}",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
-        "self_play_moves_per_sec": world * E * args.steps / elapsed,
+        "self_play_moves_per_sec": moves_played / elapsed,
+        "moves_played": moves_played, "moves_scheduled": world * E * args.steps,
     }
 
     if rank == 0:
