@@ -89,7 +89,8 @@ typedef struct mzmcts_root_stats {
 typedef struct mzmcts_profile {
     double select_ms, expand_backup_ms, root_ms, fused_ms; /* summed kernel durations      */
     int64_t select_launches, expand_backup_launches, root_launches, fused_launches;
-    int64_t select_depth_sum;  /* sum over launches and trees of the select depth (d-bar) */
+    int64_t select_depth_sum;  /* sum over launches and trees of the select depth (d-bar); move batches add
+                                * to it only while profiling is on (mzmcts_set_profiling) */
     int64_t simulations;       /* tree-simulations executed (launches x active trees)     */
 } mzmcts_profile;
 

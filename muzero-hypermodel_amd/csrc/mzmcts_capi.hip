@@ -1596,10 +1596,17 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
         for (int e = lo; e < hi; ++e) {
             const bool active = c.nlegal[e] > 0;
             int k = 0;  // moves of this env that were searched: the first k of the batch
-            if (active)
-                while (k < M && reinterpret_cast<const int32_t*>(block(k, b.o_actions))[e] >= 0) ++k;
+            if (active) {
+                // played moves are a prefix of the batch (a stall is sticky, a move limit is a prefix): if the last
+                // one ran, all of them did -- one read instead of M for nearly every env
+                if (M > 0 && reinterpret_cast<const int32_t*>(block(M - 1, b.o_actions))[e] >= 0)
+                    k = M;
+                else
+                    while (k < M && reinterpret_cast<const int32_t*>(block(k, b.o_actions))[e] >= 0) ++k;
+            }
             if (moves_done) moves_done[e] = k;
-            for (int m = 0; m < M; ++m) {
+            const bool per_move = actions || visits || root_value_sum || root_predicted || max_depth || eng->profiling;
+            for (int m = 0; per_move && m < M; ++m) {
                 const bool live = m < k;
                 const size_t me = static_cast<size_t>(m) * E + e;
                 if (actions) actions[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_actions))[e] : -1;
@@ -1609,7 +1616,7 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
                 if (root_value_sum) root_value_sum[me] = live ? reinterpret_cast<const double*>(block(m, b.o_rvs))[e] : 0.0;
                 if (root_predicted) root_predicted[me] = live ? reinterpret_cast<const float*>(block(m, b.o_pred))[e] : 0.f;
                 if (max_depth) max_depth[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_depth))[e] : 0;
-                if (live) local_depth += reinterpret_cast<const int32_t*>(block(m, b.o_dsum))[e];
+                if (live && eng->profiling) local_depth += reinterpret_cast<const int32_t*>(block(m, b.o_dsum))[e];
             }
             local += k;
             // The mirror ran ahead over this batch (and over the next one, if it is pre-drawn): put it where the
