@@ -1,29 +1,45 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MCTS simulations/sec (whole job) on BASELINE.json config #2 --
-CartPole-v1, fully-connected net (the reference's trained checkpoint), 4096 envs x 50 sims per GPU.
+"""Headline benchmark: MCTS simulations/sec (whole job) of the self-play search path.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N] [--workload cartpole|tictactoe|connect4|atari84] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one move of self-play search for every env on the rank: root inference + root expansion
-with Dirichlet noise, 50 x (select -> recurrent_inference -> expand/backup), readout, action sampling
-(synthetic fixed-weight rollouts, observations uniform(-0.05, 0.05) resident in HBM).
-value = (ranks x envs x sims x steps) / max-over-ranks wall time; weak scaling (fixed envs per GPU);
-each rank owns envs [rank*E, (rank+1)*E) with RNG seeds config.seed + global env index, and every
-`--bcast-every` steps all ranks take rank 0's flat weight buffer by RCCL broadcast.
+Workloads (BASELINE.json `configs`; default = config #2, the one the metric is quoted on):
+  cartpole    #2  CartPole-v1, fully-connected net (the reference's trained checkpoint), 4096 envs x 50 sims per GPU,
+                  whole move in ONE HIP launch (network in-kernel, trees in LDS), moves queued in batches
+  tictactoe   #3  residual net 1 block x 16 channels, 25 sims, masked roots, 4096 envs per GPU, lock-step
+  connect4    #4  residual net 3 blocks x 64 channels, 200 sims, 1024 envs per GPU, lock-step
+  atari84     #5  84x84x4 frames -> CNN down-sampler -> 2 blocks x 16 channels at 6x6, 50 sims, 1024 envs per GPU
+(lock-step = per simulation: select kernel -> recurrent inference through PyTorch-ROCm + HIP network kernels ->
+expand/backup kernel; the S-simulation loop replayed from one hipGraph.  Synthetic weights for the residual nets.)
+
+One "step" = one move of self-play search for every env on the rank: root inference + root expansion with Dirichlet
+noise, S x (select -> recurrent_inference -> expand/backup), readout, action sampling (synthetic
+fixed-weight rollouts, observations resident in HBM).  value = simulations of all ranks / max-over-ranks wall time;
+weak scaling (fixed envs per GPU); rank g owns envs [g*E, (g+1)*E) with RNG seeds config.seed + global env index, and
+every `--bcast-every` steps all ranks take rank 0's flat weight buffer by one RCCL broadcast.
+
+Launch: with N > 1 and no WORLD_SIZE in the environment this script starts its N ranks itself (fresh child
+processes, decided before anything touches the GPU) and relays rank 0's JSON line; under torch.distributed.run it
+joins the group it is given.  The timed region is K steps repeated until it lasts >= --min-seconds (a 20-step CartPole
+run would otherwise be a 5 ms sample): `steps` stays K, `timed_steps` says how many were timed, `ms_per_step` is
+per step.
 
 Prints ONE JSON line (rank 0).  Extra legs on rank 0:
-  roofline      HIP-event-bracketed eager pass of the same workload (events cannot bracket kernels
-                inside a replayed hipGraph): per-kernel mean duration, algorithmic bytes per launch
-                (SURVEY.md section 8d formula with the measured mean select depth) -> achieved GB/s vs 8 TB/s
-  cpu_baseline  N=1 only: the C oracle (a port of the reference's one-tree-at-a-time loop) on one host
-                core over a bounded sample of the same observations
+  roofline      HIP-event pass of the same workload: per-kernel mean duration, algorithmic bytes per launch (SURVEY.md
+                section 8d formula with the measured mean select depth) vs 8 TB/s for the tree kernels, network FLOPs vs
+                the fp32 matrix peak for the inference launches; the dominant one is `roofline`, all are in `kernels`
+  cpu_baseline  N = 1 only: the oracle's port of the reference's one-tree-at-a-time loop on one host core and on all
+                available host cores (one process per core), bounded samples of the same workload
 """
 import argparse
 import importlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,28 +52,42 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-# oracle-port / reference ratio measured in the build container on the same inputs (1 thread, Xeon
-# 2.1 GHz): C port 324e3 sims/s vs reference Python 1559 sims/s (tests/golden/g10_reference_speed.npz)
-RHO_PORT_OVER_REFERENCE = 208.0
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_* / fp32 VALU peak (same guide); the residual nets run in fp32
+# reference Python / oracle port, 1 thread, same inputs, measured in the build container (Xeon 2.1 GHz):
+# CartPole: C port 324e3 sims/s vs reference 1559 sims/s (tests/golden/g10_reference_speed.npz).  An extrapolation
+# to another CPU, kept only as a labelled side figure; `cpu_baseline.value` is the port itself.
+RHO_PORT_OVER_REFERENCE = {"cartpole": 208.0}
+
+WORKLOADS = {
+    "cartpole": dict(envs=4096, baseline_config=2),
+    "tictactoe": dict(envs=4096, baseline_config=3),
+    "connect4": dict(envs=1024, baseline_config=4),
+    "atari84": dict(envs=1024, baseline_config=5),
+}
 
 
 def pkg(sub):
     return importlib.import_module(f"muzero-hypermodel_amd.{sub}")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=4096, help="envs (trees) per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cartpole")
+    ap.add_argument("--envs", type=int, default=0, help="envs (trees) per GPU (0 = the workload's default)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the K timed steps are repeated until the timed region lasts at least this long")
     ap.add_argument("--bcast-every", type=int, default=50, help="weight broadcast period in steps (N>1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="budget of each cpu_baseline leg, 1 core and all cores (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores leg (0 = every available core)")
     ap.add_argument("--obs-sets", type=int, default=8)
     ap.add_argument("--mode", choices=["fused", "lockstep"], default="fused",
-                    help="fused: whole move in one HIP launch (FC net in-kernel, trees in LDS); "
+                    help="cartpole only.  fused: whole move in one HIP launch (FC net in-kernel, trees in LDS); "
                          "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
@@ -66,217 +96,501 @@ def parse_args():
     ap.add_argument("--moves-per-batch", type=int, default=50,
                     help="fused mode: moves queued back to back per host round trip (mzmcts_moves_*); "
                          "0 = one host round trip per move, pipelined over --groups env groups")
-    return ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU: run launch, rendezvous (gloo), weight broadcast, timing reduction and the JSON relay "
+                         "with the search replaced by a sleep -- a test of the N>1 plumbing, never a measurement")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
+# ----------------------------------------------------------------------------------------------------------------
+# self-launch (N > 1 without torch.distributed.run)
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start `args.gpus` fresh rank processes of this script and relay rank 0's JSON line.  Runs before anything in
+    this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image); children
+    are new processes, never an exec of one that holds the GPU.  Mirrors muzero.py:170-186 (N self-play workers with
+    seeds config.seed + i), without Ray."""
+    n = args.gpus
+    env = dict(os.environ)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MZ_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not args.rehearse_cpu:
+        visible = torch.cuda.device_count()
+        if visible == 0:
+            print("bench.py needs MI355X GPUs (none visible); --rehearse-cpu exercises the N>1 plumbing on CPU",
+                  file=sys.stderr)
+            return 2
+        if visible < n:
+            # fewer GPUs than ranks: every rank shares cuda:0 and the group runs over gloo (RCCL refuses two ranks
+            # on one device).  The JSON line says so ("rehearsal"); it is never a measurement.
+            env["MZ_REHEARSE_ON_ONE_GPU"] = "1"
+    procs = []
+    for rank in range(n):
+        child_env = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=child_env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True))
+    line = procs[0].stdout.read()
+    codes = []
+    deadline = time.time() + 3400
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(-9)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return bad[0] if bad else 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
+def workload_config(name):
+    if name == "atari84":
+        return pkg("games.breakout").atari84_config()
+    return pkg(f"games.{name}").MuZeroConfig()
+
+
+def workload_weights(name, config):
     from parity_helpers import load_golden
-    actor_mod, cartpole, engine_mod = pkg("actor"), pkg("games.cartpole"), pkg("engine")
+    if name == "cartpole":
+        w = load_golden("cartpole_weights")
+        return {k: torch.from_numpy(w[k]) for k in w.files}, "reference checkpoint"
+    from synth import synthetic_state_dict
+    template = pkg("models").MuZeroNetwork(config).state_dict()
+    return ({k: torch.from_numpy(v) for k, v in synthetic_state_dict(template, 0).items()},
+            "synthetic (tests/golden/synth.py seed 0)")
+
+
+def synthetic_positions(name, config, E, rs, device, sets):
+    """Resident observation batches + root legal sets: CartPole uniform(-0.05, 0.05); board
+    games random planes with at least one illegal root action per env; Atari-like uniform(0, 1) frames."""
+    A, P = len(config.action_space), len(config.players)
+    C, H, W = config.observation_shape
+    obs = []
+    for _ in range(sets):
+        if name == "cartpole":
+            o = rs.uniform(-0.05, 0.05, (E, C, H, W)).astype(np.float32)
+        elif name == "atari84":
+            o = rs.uniform(0, 1, (E, C, H, W)).astype(np.float32)
+        else:
+            o = rs.randint(0, 2, (E, C, H, W)).astype(np.float32)
+            o[:, 2] = 1.0
+        obs.append(torch.from_numpy(o).to(device))
+    legal = np.zeros((E, A), np.int32)
+    num_legal = np.zeros(E, np.int32)
+    if P == 1:
+        legal[:] = np.arange(A, dtype=np.int32)
+        num_legal[:] = A
+    else:
+        for e in range(E):
+            k = int(rs.randint(max(1, A // 2), A))
+            legal[e, :k] = np.sort(rs.choice(A, size=k, replace=False))
+            num_legal[e] = k
+    to_play = rs.randint(0, P, E).astype(np.int32) if P > 1 else np.zeros(E, np.int32)
+    return obs, legal, num_legal, to_play
+
+
+def _conv_flops(c_in, c_out, k, h, w):
+    return 2 * c_in * c_out * k * k * h * w
+
+
+def _mlp_flops(sizes):
+    return sum(2 * a * b for a, b in zip(sizes[:-1], sizes[1:]))
+
+
+def recurrent_inference_flops(config):
+    """FLOPs (2 per multiply-add) of one recurrent_inference of one sample (reference models.py:399-522, 128-195);
+    matches SURVEY.md section 8's table, which was measured with torch's flop counter."""
+    A, F = len(config.action_space), 2 * config.support_size + 1
+    if config.network == "fullyconnected":
+        enc = config.encoding_size
+        return (_mlp_flops([enc + A] + list(config.fc_dynamics_layers) + [enc])
+                + _mlp_flops([enc] + list(config.fc_reward_layers) + [F])
+                + _mlp_flops([enc] + list(config.fc_value_layers) + [F])
+                + _mlp_flops([enc] + list(config.fc_policy_layers) + [A]))
+    _, h, w = config.observation_shape
+    if config.downsample:
+        h, w = math.ceil(h / 16), math.ceil(w / 16)
+    c, b = config.channels, config.blocks
+    plane = h * w
+    flops = _conv_flops(c + 1, c, 3, h, w) + b * 2 * _conv_flops(c, c, 3, h, w)          # dynamics tower
+    flops += b * 2 * _conv_flops(c, c, 3, h, w)                                          # prediction tower
+    for reduced, layers, out in ((config.reduced_channels_reward, config.resnet_fc_reward_layers, F),
+                                 (config.reduced_channels_value, config.resnet_fc_value_layers, F),
+                                 (config.reduced_channels_policy, config.resnet_fc_policy_layers, A)):
+        flops += _conv_flops(c, reduced, 1, h, w) + _mlp_flops([reduced * plane] + list(layers) + [out])
+    return flops
+
+
+class Workload:
+    """One rank's shard of a benchmark workload: model replica, engine, resident synthetic inputs."""
+
+    def __init__(self, args, rank, world, device):
+        self.args, self.rank, self.world, self.device = args, rank, world, device
+        self.name = args.workload
+        self.config = workload_config(self.name)
+        self.E = args.envs or WORKLOADS[self.name]["envs"]
+        self.S, self.A = self.config.num_simulations, len(self.config.action_space)
+        weights, self.weights_kind = workload_weights(self.name, self.config)
+        self.fused = self.name == "cartpole" and args.mode == "fused"
+        group = args.group if args.group else (16 if self.fused else 0)
+        actor_mod = pkg("actor")
+        self.actor = actor_mod.SearchActor(self.config, weights, self.E, rank=rank, device=device,
+                                           use_graph=not args.no_graph, group_width=group, fused_fc=self.fused)
+        self.engine, self.model = self.actor.engine, self.actor.model
+        self.engine.fused_hidden_in_lds = not args.hidden_in_hbm
+        rs = np.random.RandomState(123 + rank)
+        self.obs_sets, self.legal, self.num_legal, self.to_play = synthetic_positions(
+            self.name, self.config, self.E, rs, device, args.obs_sets)
+        self.temperature = np.ones(self.E, dtype=np.float64)
+        self.batched = self.fused and args.moves_per_batch > 0
+        self.pipe = None
+        self.bcast = world > 1 and args.bcast_every > 0
+        self.refreshes = 0
+        if self.batched:
+            self.engine.set_fused_options("auto", publish_tree=False)     # MCTS.run's callers consume the root only
+            self.flat_obs = [o.reshape(self.E, -1).contiguous() for o in self.obs_sets]
+        elif self.fused and args.groups > 1:
+            self._init_pipeline(actor_mod, group)
+
+    # ---- weight refresh (the one exchange step of the path) ---------------------------------------------------------
+    def refresh(self):
+        self.actor.refresh_weights(src=0)
+        self.refreshes += 1
+
+    # ---- one move for every env, one host round trip per move -------------------------------------------------------
+    def search_only_step(self, i):
+        """One move on the full-size engine, no collectives (also the roofline leg's step)."""
+        e = self.engine
+        e.search(self.model, self.obs_sets[i % len(self.obs_sets)], self.legal, self.to_play, True,
+                 num_legal=self.num_legal)
+        e.sample_actions(self.temperature)
+
+    def one_step(self, i):
+        if self.bcast and i % self.args.bcast_every == 0:
+            if self.pipe:
+                torch.cuda.synchronize(self.device)          # weights are shared by all groups' kernels
+            self.refresh()
+        if self.pipe:
+            self._pipe_step(i)
+        else:
+            self.search_only_step(i)
+
+    # ---- fused CartPole, several env groups on separate streams -----------------------------------------------------
+    def _init_pipeline(self, actor_mod, group):
+        n = self.args.groups
+        self.pipe = pkg("engine").PipelinedSearch(self.config, self.E, self.model, self.actor.flat, groups=n,
+                                                  device=self.device,
+                                                  seeds=actor_mod.shard_seeds(self.config.seed, self.rank, self.E),
+                                                  group_width=group)
+        per = self.E // n
+        self.g_obs = [[o.reshape(self.E, -1)[self.pipe.slice(g)].contiguous() for g in range(n)] for o in self.obs_sets]
+        self.g_in = (self.legal[:per], self.num_legal[:per], self.to_play[:per], self.temperature[:per])
+        self.started = [False] * n
+
+    def _pipe_step(self, i):
+        g_legal, g_nl, g_tp, g_temp = self.g_in
+        for g in range(self.args.groups):
+            if self.started[g]:
+                self.pipe.finish(g)
+                self.pipe.engines[g].sample_actions(g_temp)
+            self.pipe.begin(g, self.g_obs[i % len(self.obs_sets)][g], g_legal, g_tp, True, num_legal=g_nl)
+            self.started[g] = True
+
+    def drain(self):
+        if not self.pipe:
+            return
+        for g in range(self.args.groups):
+            if self.started[g]:
+                self.pipe.finish(g)
+                self.pipe.engines[g].sample_actions(self.g_in[3])
+                self.started[g] = False
+
+    # ---- fused CartPole, moves queued in batches (no host round trip inside a batch) --------------------------------
+    def batch_sizes(self, start, count):
+        i, out = start, []
+        while count > 0:
+            b = min(self.args.moves_per_batch, count)
+            if self.bcast:
+                b = min(b, self.args.bcast_every - i % self.args.bcast_every)
+            out.append((i, b))
+            i += b
+            count -= b
+        return out
+
+    def prepare(self, n_moves):
+        self.engine.moves_prepare(n_moves, self.legal, self.to_play, self.temperature, True, num_legal=self.num_legal)
+
+    def run_plan(self, plan, trailing_predraw):
+        """Batches plan[i] = (first step, moves); the first one must already be drawn and uploaded.  The host draws a
+        batch's exploration noise while the previous batch runs and collects actions / visit counts / root values of a
+        batch when it is done; kernels of one batch follow each other without host round trips.  trailing_predraw =
+        (moves) draws one more batch during the last one (left uploaded-ready)."""
+        engine, trace = self.engine, os.environ.get("MZ_BENCH_TRACE")
+        played = 0
+        for n, (i, b) in enumerate(plan):
+            if self.bcast and i % self.args.bcast_every == 0:
+                self.refresh()
+            t = [time.perf_counter()]
+            for k in range(b):
+                engine.moves_enqueue(self.flat_obs[(i + k) % len(self.flat_obs)])
+            t.append(time.perf_counter())
+            nxt = plan[n + 1][1] if n + 1 < len(plan) else trailing_predraw
+            if nxt:
+                engine.moves_predraw_next(nxt, self.legal, self.to_play, self.temperature, True, num_legal=self.num_legal)
+            t.append(time.perf_counter())
+            out = engine.moves_collect(copy=bool(os.environ.get("MZ_BENCH_COPY")))   # default: views of the download ring
+            played += int(out["moves_done"].sum())   # an env whose stream left the pre-drawn path sits out the rest
+            t.append(time.perf_counter())
+            if n + 1 < len(plan):
+                engine.moves_submit_next()
+            t.append(time.perf_counter())
+            self.pending_predraw = nxt if n + 1 == len(plan) else 0
+            if trace:
+                print(f"[bench] batch of {b}: enqueue {1e3 * (t[1] - t[0]):.2f} ms, predraw {1e3 * (t[2] - t[1]):.2f}, "
+                      f"collect {1e3 * (t[3] - t[2]):.2f}, submit {1e3 * (t[4] - t[3]):.2f}; moves done min "
+                      f"{int(out['moves_done'].min())}", file=sys.stderr, flush=True)
+        return played
+
+    def close(self):
+        if self.pipe:
+            self.pipe.close()
+        self.actor.close()
+
+
+def run_steps(wl, first, count, barrier, next_first=0):
+    """`count` steps starting at step index `first`, bracketed by barrier + synchronize; returns (seconds, moves)."""
+    if wl.batched:
+        plan = wl.batch_sizes(first, count)
+        drawn_ahead = getattr(wl, "pending_predraw", 0) == plan[0][1]
+        if not drawn_ahead:                                  # the batch drawn ahead has another size: draw this one now
+            wl.engine.moves_discard_next()
+            wl.prepare(plan[0][1])
+        barrier()
+        t0 = time.perf_counter()
+        # every timed batch is run and collected inside the timed region, and so is one noise draw per batch (the last
+        # batch's draw produces rows nobody runs: it stands in for the first batch's, done before the timer started)
+        if drawn_ahead:
+            wl.engine.moves_submit_next()
+        played = wl.run_plan(plan, next_first or plan[0][1])
+        barrier()
+        return time.perf_counter() - t0, played
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(first, first + count):
+        wl.one_step(i)
+    wl.drain()                                               # every queued move is finished inside the timed region
+    barrier()
+    return time.perf_counter() - t0, wl.E * count
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
+    actor_mod = pkg("actor")
     rank, world, local_rank = actor_mod.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = torch.distributed
+    rehearsal = bool(os.environ.get("MZ_REHEARSE_ON_ONE_GPU")) and world > 1
 
-    config = cartpole.MuZeroConfig()
-    E, S, A = args.envs, config.num_simulations, len(config.action_space)
-    w = load_golden("cartpole_weights")
-    weights = {k: torch.from_numpy(w[k]) for k in w.files}
-    fused = args.mode == "fused"
-    group = args.group if args.group else (16 if fused else 0)
-    actor = actor_mod.SearchActor(config, weights, E, rank=rank, device=device, use_graph=not args.no_graph,
-                                  group_width=group, fused_fc=fused)
-    engine, model = actor.engine, actor.model
-    engine.fused_hidden_in_lds = not args.hidden_in_hbm
-
-    rs = np.random.RandomState(123 + rank)
-    obs_sets = [torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)).to(device)
-                for _ in range(args.obs_sets)]
-    legal = np.tile(np.arange(A, dtype=np.int32), (E, 1))
-    num_legal = np.full(E, A, dtype=np.int32)
-    to_play = np.zeros(E, dtype=np.int32)
-    temperature = np.ones(E, dtype=np.float64)
-
-    def one_step(i):
-        if world > 1 and args.bcast_every and i % args.bcast_every == 0:
-            actor.refresh_weights(src=0)
-        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
-        engine.sample_actions(temperature)
-
-    def search_only_step(i):
-        """One move on the single full-size engine, no collectives (roofline leg, rank 0 only)."""
-        engine.search(model, obs_sets[i % len(obs_sets)], legal, to_play, True, num_legal=num_legal)
-        engine.sample_actions(temperature)
-
-    pipe = None
-    batched = fused and args.moves_per_batch > 0
-    if batched:
-        engine.set_fused_options("auto", publish_tree=False)     # MCTS.run's callers consume the root only
-        flat_obs = [o.reshape(E, -1).contiguous() for o in obs_sets]
-
-        def batch_sizes(start, count):
-            i, out = start, []
-            while count > 0:
-                b = min(args.moves_per_batch, count)
-                if world > 1 and args.bcast_every:
-                    b = min(b, args.bcast_every - i % args.bcast_every)
-                out.append((i, b))
-                i += b
-                count -= b
-            return out
-
-        def run_plan(plan, trailing_predraw):
-            """Batches plan[i] = (first step, moves); the first one must already be drawn and uploaded.  The host
-            draws a batch's exploration noise while the previous batch runs and collects actions / visit counts /
-            root values of a batch when it is done; kernels of one batch follow each other without host round
-            trips.  trailing_predraw = (moves) draws one more batch during the last one (left uploaded-ready)."""
-            trace = os.environ.get("MZ_BENCH_TRACE")
-            played = 0
-            for n, (i, b) in enumerate(plan):
-                if world > 1 and args.bcast_every and i % args.bcast_every == 0:
-                    actor.refresh_weights(src=0)
-                t = [time.perf_counter()]
-                for k in range(b):
-                    engine.moves_enqueue(flat_obs[(i + k) % len(flat_obs)])
-                t.append(time.perf_counter())
-                nxt = plan[n + 1][1] if n + 1 < len(plan) else trailing_predraw
-                if nxt:
-                    engine.moves_predraw_next(nxt, legal, to_play, temperature, True, num_legal=num_legal)
-                t.append(time.perf_counter())
-                out = engine.moves_collect(copy=bool(os.environ.get("MZ_BENCH_COPY")))   # default: views of the download ring
-                played += int(out["moves_done"].sum())   # an env whose stream left the pre-drawn path sits out the rest
-                t.append(time.perf_counter())
-                if n + 1 < len(plan):
-                    engine.moves_submit_next()
-                t.append(time.perf_counter())
-                if trace:
-                    print(f"[bench] batch of {b}: enqueue {1e3 * (t[1] - t[0]):.2f} ms, predraw {1e3 * (t[2] - t[1]):.2f}, "
-                          f"collect {1e3 * (t[3] - t[2]):.2f}, submit {1e3 * (t[4] - t[3]):.2f}; moves done min "
-                          f"{int(out['moves_done'].min())}", file=sys.stderr, flush=True)
-            return played
-    elif fused and args.groups > 1:
-        # n env groups on n streams: one group's host work overlaps the other groups' kernels
-        n = args.groups
-        pipe = engine_mod.PipelinedSearch(config, E, model, actor.flat, groups=n, device=device,
-                                          seeds=actor_mod.shard_seeds(config.seed, rank, E), group_width=group)
-        per = E // n
-        g_obs = [[o.reshape(E, -1)[pipe.slice(g)].contiguous() for g in range(n)] for o in obs_sets]
-        g_legal, g_nl, g_tp, g_temp = legal[:per], num_legal[:per], to_play[:per], temperature[:per]
-        started = [False] * n
-
-        def one_step(i):  # noqa: F811 -- one move for every group, pipelined across groups and steps
-            if world > 1 and args.bcast_every and i % args.bcast_every == 0:
-                torch.cuda.synchronize(device)          # weights are shared by all groups' kernels
-                actor.refresh_weights(src=0)
-            for g in range(n):
-                if started[g]:
-                    pipe.finish(g)
-                    pipe.engines[g].sample_actions(g_temp)
-                pipe.begin(g, g_obs[i % len(obs_sets)][g], g_legal, g_tp, True, num_legal=g_nl)
-                started[g] = True
-
-        def drain():
-            for g in range(n):
-                if started[g]:
-                    pipe.finish(g)
-                    pipe.engines[g].sample_actions(g_temp)
-                    started[g] = False
+    wl = Workload(args, rank, world, device)
+    E, S, A = wl.E, wl.S, wl.A
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize(device)
 
-    if batched:
-        warm, timed = batch_sizes(0, args.warmup), batch_sizes(args.warmup, args.steps)
-        engine.moves_prepare(max(b for _, b in warm + timed), legal, to_play, temperature, True, num_legal=num_legal)
-        engine.moves_collect()                           # (sizes the batch buffers once; nothing was queued)
-        if warm:
-            engine.moves_prepare(warm[0][1], legal, to_play, temperature, True, num_legal=num_legal)
-            run_plan(warm, timed[0][1])                  # steady state: the first timed batch is drawn during warm-up
-    else:
-        for i in range(args.warmup):
-            one_step(i)
-    if pipe:
-        drain()
-    barrier()
-    t0 = time.perf_counter()
-    if batched:
-        # every timed batch is uploaded, run and collected inside the timed region, and so is one noise draw per
-        # batch (the last batch's draw produces rows nobody runs: it stands in for the first batch's, done above)
-        if warm:
-            engine.moves_submit_next()
-        else:
-            engine.moves_prepare(timed[0][1], legal, to_play, temperature, True, num_legal=num_legal)
-        moves_played = run_plan(timed, timed[-1][1])
-    else:
-        for i in range(args.steps):
-            one_step(i)
-        moves_played = E * args.steps
-    if pipe:
-        drain()                                          # every queued move is finished inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if batched:
-        engine.moves_discard_next()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if world > 1:
-        t = torch.tensor([moves_played], dtype=torch.int64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        moves_played = int(t.item())
-    # only searches that really ran count: in move batches an env whose tie-break words differ from the pre-drawn
-    # assumption sits out the rest of its batch (DESIGN.md section 3), so moves_played <= world * E * steps
-    sims_total = moves_played * S
-    value = sims_total / elapsed
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
+    def gather(x):
+        if world == 1:
+            return [x]
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    K, W = args.steps, args.warmup
+    # ---- warm-up: W untimed steps, then an untimed probe of K steps that sizes the timed region ----------------------
+    if wl.batched:
+        plan_all = wl.batch_sizes(0, max(W, 1) + K)
+        wl.prepare(max(b for _, b in plan_all + wl.batch_sizes(0, args.moves_per_batch)))
+        wl.engine.moves_collect()                        # (sizes the batch buffers once; nothing was queued)
+        warm = wl.batch_sizes(0, max(W, 1))
+        wl.prepare(warm[0][1])
+        wl.run_plan(warm, wl.batch_sizes(max(W, 1), K)[0][1])   # steady state: the next batch is drawn during warm-up
+    else:
+        for i in range(W):
+            wl.one_step(i)
+        wl.drain()
+    next_first = wl.batch_sizes(max(W, 1) + K, 1 << 30)[0][1] if wl.batched else 0
+    probe_s, _ = run_steps(wl, max(W, 1), K, barrier, next_first)
+    probe_s = reduce_max(probe_s)
+    repeats = max(1, int(math.ceil(args.min_seconds / max(probe_s, 1e-9))))
+    # ---- timed region: exactly repeats x K steps ---------------------------------------------------------------------
+    refreshes_before = wl.refreshes
+    elapsed, moves_played = run_steps(wl, max(W, 1) + K, repeats * K, barrier)
+    if wl.batched:
+        wl.engine.moves_discard_next()
+    per_rank = gather((elapsed, moves_played))
+    elapsed = max(e for e, _ in per_rank)
+    moves_played = sum(m for _, m in per_rank)
+    timed_steps = repeats * K
+    # only searches that really ran count: in move batches an env whose tie-break words differ from the pre-drawn
+    # assumption sits out the rest of its batch (DESIGN.md section 3), so moves_played <= world * E * timed_steps
+    value = moves_played * S / elapsed
+
+    # ---- the weight refresh by itself (not part of `value`; N > 1) ---------------------------------------------------
+    bcast_us = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            wl.actor.flat.broadcast(src=0)
+        barrier()
+        bcast_us = reduce_max(1e6 * (time.perf_counter() - t0) / 20)
+
+    fused, batched = wl.fused, wl.batched
+    engine = wl.engine
+    network = (f"fullyconnected ({wl.weights_kind}), fp32 inference "
+               + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm")) if wl.name == "cartpole" else \
+        (f"resnet {wl.config.blocks} blocks x {wl.config.channels} channels ({wl.weights_kind}), fp32 inference through "
+         "PyTorch-ROCm + HIP network kernels")
     result = {
         "metric": "mcts_simulations_per_sec", "value": value, "unit": "simulations/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / timed_steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"cartpole_fc_{E}envs_x_{S}sims", "envs_per_gpu": E, "simulations": S,
-                   "actions": A,
-                   "network": "fullyconnected (reference checkpoint), fp32 inference "
-                              + ("in the fused HIP kernel" if fused else "through PyTorch-ROCm"),
-                   "mode": args.mode, "lanes_per_tree": engine.group_width(),
+        "config": {"workload": f"{wl.name}_{E}envs_x_{S}sims", "baseline_config": WORKLOADS[wl.name]["baseline_config"],
+                   "envs_per_gpu": E, "simulations": S, "actions": A, "network": network,
+                   "mode": "fused" if fused else "lockstep", "lanes_per_tree": engine.group_width(),
                    "env_groups_per_gpu": args.groups if (fused and not batched and args.groups > 1) else 1,
                    "moves_per_host_round_trip": args.moves_per_batch if batched else 1,
                    "fused_kernel": engine.fused_variant() if fused else None,
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
                    "parallelism": f"actors{world}",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
+        "timed_steps": timed_steps, "timed_seconds": elapsed, "repeats_of_steps": repeats,
         "self_play_moves_per_sec": moves_played / elapsed,
-        "moves_played": moves_played, "moves_scheduled": world * E * args.steps,
+        "moves_played": moves_played, "moves_scheduled": world * E * timed_steps,
     }
+    if world > 1:
+        backend = dist.get_backend()
+        result.update({
+            "per_rank_simulations_per_sec": [m * S / e for e, m in per_rank],
+            "collective_backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+            "weight_refreshes_in_timed_region": wl.refreshes - refreshes_before,
+            "weight_broadcast_us": bcast_us, "weight_bytes": wl.actor.flat.nbytes(),
+            "self_launched": bool(os.environ.get("MZ_BENCH_SELF_LAUNCHED"))})
+        if rehearsal:
+            result["rehearsal"] = f"{world} ranks share cuda:0 over gloo (fewer GPUs than ranks): not a measurement"
 
     if rank == 0:
         if args.profile_steps > 0:
-            result["roofline"], result["kernels"] = roofline_leg(engine, search_only_step, args.profile_steps, device)
+            result["roofline"], result["kernels"] = roofline_leg(wl, args.profile_steps, device)
         if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline_leg(config, w, args.cpu_seconds)
-            result["speedup_vs_reference_equivalent"] = value / result["cpu_baseline"]["reference_equivalent_value"]
+            result["cpu_baseline"] = cpu_baseline_leg(wl.name, wl.config, args.cpu_seconds, args.cpu_workers)
+            result["speedup_vs_cpu_port_1core"] = value / result["cpu_baseline"]["value"]
+            if result["cpu_baseline"].get("all_cores"):
+                result["speedup_vs_cpu_port_all_cores"] = value / result["cpu_baseline"]["all_cores"]["value"]
     barrier()
     if rank == 0:
-        print(json.dumps(result))
-    actor.close()
+        print(json.dumps(result), flush=True)
+    wl.close()
     if world > 1:
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
 
 
-def roofline_leg(engine, one_step, steps, device):
-    """Eager pass with HIP events around every tree-kernel launch (same stream as the launches)."""
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 plumbing on CPU (tests/test_bench_launcher.py): no GPU, no search -- never a measurement
+# ----------------------------------------------------------------------------------------------------------------
+def rehearse_cpu(args):
+    dist = torch.distributed
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    actor_mod, weights_mod, models = pkg("actor"), pkg("weights"), pkg("models")
+    config = workload_config(args.workload)
+    weights, _ = workload_weights(args.workload, config)
+    model = models.MuZeroNetwork(config)
+    model.set_weights(weights)
+    model.eval()
+    flat = weights_mod.FlatWeights(model)
+    if rank != 0:
+        with torch.no_grad():
+            flat.flat.add_(float(rank))                      # stale weights everywhere but on rank 0
+    seeds = actor_mod.shard_seeds(config.seed, rank, 4)
+    E = 4
+    refreshes = 0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if world > 1 and args.bcast_every and i % args.bcast_every == 0:
+            flat.broadcast(src=0)
+            refreshes += 1
+        time.sleep(0.001)                                    # stands in for one move of search
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    checksum = float(flat.flat.double().sum())
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (elapsed, checksum, seeds))
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    else:
+        gathered = [(elapsed, checksum, seeds)]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "launcher_rehearsal_not_a_measurement", "value": None, "unit": None, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "collective_backend": "gloo", "rccl_ranks": 0, "weight_refreshes": refreshes,
+            "weights_identical_after_refresh": len({c for _, c, _ in gathered}) == 1,
+            "rank_seeds": [s for _, _, s in gathered], "envs_per_rank": E,
+            "self_launched": bool(os.environ.get("MZ_BENCH_SELF_LAUNCHED")),
+            "config": {"workload": f"{args.workload}_plumbing_only"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# roofline leg
+# ----------------------------------------------------------------------------------------------------------------
+def roofline_leg(wl, steps, device):
+    """Eager pass with HIP events around every tree-kernel launch (bound to the dispatch, on the launch stream); for
+    the lock-step workloads also torch events (same stream: the network kernels are launched on torch's current
+    stream) around the network launches of one recurrent inference."""
+    engine = wl.engine
     engine.set_profiling(True)
     engine.get_profile(reset=True)
     for i in range(2):
-        one_step(i)
+        wl.search_only_step(i)
     torch.cuda.synchronize(device)
     engine.get_profile(reset=True)
     for i in range(steps):
-        one_step(i)
+        wl.search_only_step(i)
     torch.cuda.synchronize(device)
     prof = engine.get_profile(reset=True)
     engine.set_profiling(False)
@@ -292,10 +606,23 @@ def roofline_leg(engine, one_step, steps, device):
         if prof[n_key] == 0:
             continue
         avg_us = 1e3 * prof[ms_key] / prof[n_key]
-        kernels[name] = {"avg_us": avg_us, "launches": prof[n_key], "algorithmic_bytes_per_launch": per_launch,
-                         "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None}
+        kernels[name] = {"bound": "hbm", "avg_us": avg_us, "launches": prof[n_key],
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None,
+                         "frac_of_hbm_peak": per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS if avg_us > 0 else None}
+    if not wl.fused:
+        kernels["recurrent_inference"] = network_leg(wl, device)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
     d = kernels[dominant]
+    if d["bound"] == "mfma":
+        roofline = {"bound": "mfma", "kernel": d["what"], "achieved": d["achieved_TFLOPs"],
+                    "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": d["achieved_TFLOPs"] / FP32_MATRIX_PEAK_TFLOPS,
+                    "traffic": None, "avg_kernel_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
+                    "dtype": "fp32 (parity bar 1e-5 keeps the residual networks in fp32; fp32 MFMA peak = fp32 VALU peak)",
+                    "timing": "torch.cuda.Event pairs on the launch stream around the launches of one recurrent "
+                              "inference of all envs, eager, mean over repeats",
+                    "mean_select_depth": mean_depth, "algorithmic_bytes_per_simulation": bytes_sim}
+        return roofline, kernels
     kernel_name = f"mz::{dominant}_kernel"
     if dominant == "search_fused_fc" and engine.fused_variant() == "narrow":
         kernel_name = "mz::search_fused_narrow_kernel"
@@ -308,7 +635,47 @@ def roofline_leg(engine, one_step, steps, device):
                 "timing": "HIP events bound to the kernel dispatch (hipExtLaunchKernel) on the launch stream, "
                           "over a second pass of the same steps",
                 "working_set_bytes": engine.device_bytes()}
+    if traffic:
+        # what really crosses the HBM interface (PMC counters) vs the algorithmic bytes `achieved` is defined on
+        roofline["hbm_traffic_GBs"] = traffic / (d["avg_us"] * 1e-6) / 1e9
+        roofline["frac_hbm_traffic"] = roofline["hbm_traffic_GBs"] / HBM_PEAK_GBS
+        roofline["traffic_over_algorithmic"] = traffic / d["algorithmic_bytes_per_launch"]
+    if dominant == "search_fused_fc":
+        roofline["limiter"] = ("latency: the trees live in LDS (HBM sees only the published roots), one wavefront per "
+                               "SIMD at 4096 envs, so a launch lasts one tree's dependent instruction chain; "
+                               "`frac` says how far the workload is from an HBM-sized one, not how well HBM is used")
+        issue = issue_profile(kernel_name)
+        if issue:
+            roofline["issue"] = issue
     return roofline, kernels
+
+
+def network_leg(wl, device, repeats=20):
+    """Mean duration of the launches of ONE recurrent inference for all envs (dynamics + prediction networks on the
+    gathered batch), eager, and its FLOPs vs the fp32 matrix peak."""
+    engine, model = wl.engine, wl.model
+    flops = recurrent_inference_flops(wl.config) * engine.E
+    with torch.no_grad():
+        if len(engine.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
+            planes = engine.select_planes()
+            call = lambda: model.recurrent_inference_from_planes(planes, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
+        else:
+            hidden = engine.batch_hidden.view(engine.E, *engine.state_shape)
+            call = lambda: model.recurrent_inference(hidden, engine.batch_action, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize(device)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(repeats):
+            call()
+        stop.record()
+        torch.cuda.synchronize(device)
+    avg_us = 1e3 * start.elapsed_time(stop) / repeats
+    tf = flops / (avg_us * 1e-6) / 1e12
+    return {"bound": "mfma", "what": "recurrent_inference (dynamics + prediction networks, all launches of one call)",
+            "avg_us": avg_us, "launches": repeats, "flops_per_launch": flops, "achieved_TFLOPs": tf,
+            "frac_of_fp32_matrix_peak": tf / FP32_MATRIX_PEAK_TFLOPS}
 
 
 def pmc_traffic(kernel, envs):
@@ -329,32 +696,82 @@ def pmc_traffic(kernel, envs):
     return total, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline_leg(config, w, seconds):
-    """The oracle's C port of the reference loop, one host core, bounded sample of the same workload."""
-    import mz_oracle
-    weights = {k: w[k] for k in w.files}
-    net = mz_oracle.FcNet.from_config(config, weights)
-    cfg = mz_oracle.config_from_muzero(config, H=config.encoding_size)
-    obs = np.random.RandomState(123).uniform(-0.05, 0.05, (4096, 1, 1, 4)).astype(np.float32)
-    rng = mz_oracle.Rng(config.seed)
-    mz_oracle.fc_selfplay_moves(cfg, net, rng, obs[:64], 1.0)  # warm
-    t0 = time.perf_counter()
-    sims, moves = 0, 0
-    while time.perf_counter() - t0 < seconds:
-        out = mz_oracle.fc_selfplay_moves(cfg, net, rng, obs[:1024], 1.0)
-        sims += out["sims"]
-        moves += 1024
-    dt = time.perf_counter() - t0
+def issue_profile(kernel):
+    """Instruction-issue picture of the fused kernel from the committed SQ-counter pass (profiles/r*_fused_sq.json,
+    written by tools/pmc_summary.py --sq): instructions and cycles per simulation, cycles per instruction, LDS share."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fused_sq.json")))
+    if not files:
+        return None
+    data = json.load(open(files[-1]))
+    entry = data.get("kernels", {}).get(kernel) or next((v for k, v in data.get("kernels", {}).items() if kernel in k), None)
+    if entry is None:
+        return None
+    return dict(entry, source=os.path.relpath(files[-1], ROOT))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline leg (the oracle is the thing timed here, on the host cores; it is not on the product path)
+# ----------------------------------------------------------------------------------------------------------------
+def available_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:                                                     # a cgroup CPU quota is the real share of a container
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_leg(name, config, seconds, workers=0):
+    """The oracle's port of the reference loop on the host: one core, then one process per available core."""
+    worker = os.path.join(ROOT, "oracle", "cpu_selfplay.py")
+
+    def run(n_procs, secs):
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, worker, name, str(secs), str(i)], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+                 for i in range(n_procs)]
+        outs = []
+        for p in procs:
+            out, _ = p.communicate(timeout=secs + 600)
+            if p.returncode == 0 and out.strip():
+                outs.append(json.loads(out.strip().splitlines()[-1]))
+        return outs, time.perf_counter() - t0
+
     try:
         cpu_model = [line.split(":", 1)[1].strip() for line in open("/proc/cpuinfo") if line.startswith("model name")][0]
     except Exception:
         cpu_model = "unknown"
-    return {"value": sims / dt, "unit": "simulations/s", "cores": 1, "kind": "port",
-            "sample": f"{moves} moves x {config.num_simulations} sims ({dt:.1f} s), same weights and "
-                      "observation distribution, one tree at a time",
-            "cpu": cpu_model, "host_cores_available": os.cpu_count(),
-            "rho_port_over_reference": RHO_PORT_OVER_REFERENCE,
-            "reference_equivalent_value": sims / dt / RHO_PORT_OVER_REFERENCE}
+    one, _ = run(1, seconds)
+    assert one, "cpu_baseline worker failed"
+    one = one[0]
+    value = one["sims"] / one["seconds"]
+    kind_note = ("tree and FC network in C, one tree at a time" if name == "cartpole" else
+                 "tree in C, residual network at batch 1 through torch on the CPU (1 thread), one tree at a time")
+    out = {"value": value, "unit": "simulations/s", "cores": 1, "kind": "port",
+           "sample": f"{one['moves']} moves x {config.num_simulations} sims ({one['seconds']:.1f} s), same weights and "
+                     f"observation distribution; {kind_note}",
+           "cpu": cpu_model, "host_cores_available": available_cores(), "os_cpu_count": os.cpu_count()}
+    if name in RHO_PORT_OVER_REFERENCE:
+        out["rho_port_over_reference_build_container"] = RHO_PORT_OVER_REFERENCE[name]
+        out["reference_equivalent_value_extrapolated"] = value / RHO_PORT_OVER_REFERENCE[name]
+    n = workers or available_cores()
+    if name != "cartpole":
+        n = min(n, 64)                                       # each worker holds a torch runtime (~0.4 GiB)
+    if n > 1:
+        many, wall = run(n, seconds)
+        if many:
+            total = sum(o["sims"] / o["seconds"] for o in many)
+            out["all_cores"] = {"value": total, "unit": "simulations/s", "cores": len(many), "kind": "port",
+                                "sample": f"{len(many)} processes x {seconds:.0f} s, one per core, each as the 1-core leg "
+                                          f"(seeds config.seed + worker index, muzero.py:175); wall {wall:.1f} s",
+                                "per_core_value": total / len(many)}
+    return out
 
 
 if __name__ == "__main__":

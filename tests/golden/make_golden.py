@@ -394,12 +394,36 @@ def g5_connect4(ctx):
     model = build_model(models, config, None, seed=0)
     rs = numpy.random.RandomState(78)
     recs = []
-    for i, (obs, legal, tp) in enumerate(_board_positions(c4.Game, 6, rs, 30)):
-        recs.append(trace_one(models, self_play, config, model, obs, legal, tp, 100 + i))
+    # 30 positions (the first 6 are round 1's: the playout stream is consumed in order)
+    for i, (obs, legal, tp) in enumerate(_board_positions(c4.Game, 30, rs, 30)):
+        recs.append(trace_one(models, self_play, config, model, obs, legal, tp, 100 + i,
+                              temperature=1.0 if i < 6 else [1.0, 0.5, 0.25, 1.0][i % 4]))
     arrays = stack_records(recs)
     arrays.update(config_scalars(config))
     print("   connect4 mean select depth:", arrays["sim_depth"].mean())
     save("g5_connect4_traces", **arrays)
+
+
+def g5_atari84(ctx):
+    """BASELINE.json config #5 end to end: DownsampleCNN representation (models.py:278-297, 318-327) on 4 stacked
+    84x84 frames, 2 residual blocks x 16 channels at 6x6, A = 4, one player, 50 simulations."""
+    models, self_play, cfgs = ctx["models"], ctx["self_play"], ctx["configs"]
+    config = cfgs["atari84"]
+    model = build_model(models, config, None, seed=0)
+    rs = numpy.random.RandomState(84)
+    recs = []
+    for i in range(24):
+        # 8-bit frames scaled to [0, 1] like real Atari input; stored as the uint8 levels (obs = u8 / 255 in float32)
+        obs = rs.randint(0, 256, config.observation_shape).astype("uint8").astype("float32") / numpy.float32(255)
+        recs.append(trace_one(models, self_play, config, model, obs, [0, 1, 2, 3], 0, 300 + i,
+                              temperature=[1.0, 0.5, 0.25, 1.0][i % 4]))
+    arrays = stack_records(recs)
+    u8 = numpy.rint(arrays.pop("obs") * 255).astype("uint8")
+    assert numpy.array_equal(u8.astype("float32") / numpy.float32(255), numpy.stack([r["obs"] for r in recs]))
+    arrays["obs_u8"] = u8
+    arrays.update(config_scalars(config))
+    print("   atari84 mean select depth:", arrays["sim_depth"].mean())
+    save("g5_atari84_traces", **arrays)
 
 
 def g5_degenerate(ctx):
@@ -828,7 +852,7 @@ def make_configs():
 
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
-       g5_tictactoe, g5_connect4, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
+       g5_tictactoe, g5_connect4, g5_atari84, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
        g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer]
 
 

@@ -1,12 +1,12 @@
-"""Device-resident environments (include/mzenv.h) against the host Game plugins of this package, which
-are themselves pinned to the reference's envs (tests/test_host_logic.py, fixture G11)."""
+"""Device-resident environments (include/mzenv.h) against fixture G11 (playouts recorded from the reference's own
+games/tictactoe.py / games/connect4.py) and against the host Game plugins of this package."""
 import importlib
 
 import numpy as np
 import pytest
 import torch
 
-from parity_helpers import cartpole_model_and_weights, synthetic_model
+from parity_helpers import cartpole_model_and_weights, load_golden, synthetic_model
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,42 @@ def games(name):
 def dev(pkg):
     importlib.import_module("muzero-hypermodel_amd.build").build_native()
     return importlib.import_module("muzero-hypermodel_amd.games.device")
+
+
+@pytest.mark.parametrize("name", ["tictactoe", "connect4"])
+def test_device_envs_replay_reference_playouts_g11(dev, name):
+    """The HIP env kernels replay the reference's recorded playouts directly: env g plays fixture game g, all games
+    in lock step (a finished game's env is left alone: action -1); observation, legal list, to_play, reward and
+    done of every recorded position must be bit-identical."""
+    fx = load_golden(f"g11_{name}_env")
+    game, step = fx["game"].astype(int), fx["step"].astype(int)
+    G = int(game.max()) + 1
+    row_of = {(int(g), int(t)): r for r, (g, t) in enumerate(zip(game, step))}
+    length = [max(t for (g, t) in row_of if g == k) for k in range(G)]
+    envs = dev.DeviceEnvs(name, G, seeds=list(range(G)))
+    for t in range(max(length) + 1):
+        obs, legal, nl, tp = (x.cpu().numpy() for x in envs.observe())
+        actions = np.full(G, -1, np.int32)
+        for g in range(G):
+            if t > length[g]:
+                continue
+            r = row_of[(g, t)]
+            assert np.array_equal(obs[g], fx["obs"][r]), (g, t)
+            n = int(fx["n_legal"][r])
+            if not fx["done"][r]:
+                assert nl[g] == n and legal[g][:n].tolist() == fx["legal"][r][:n].tolist(), (g, t)
+                assert tp[g] == fx["to_play"][r], (g, t)
+            if t < length[g]:
+                actions[g] = int(fx["action"][row_of[(g, t + 1)]])
+        if (actions < 0).all():
+            break
+        reward, done = envs.step(actions)
+        reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
+        for g in range(G):
+            if actions[g] >= 0:
+                r = row_of[(g, t + 1)]
+                assert reward[g] == fx["reward"][r] and done[g] == bool(fx["done"][r]), (g, t)
+    envs.close()
 
 
 @pytest.mark.parametrize("name", ["tictactoe", "connect4", "cartpole"])

@@ -130,7 +130,7 @@ def test_fused_vs_reference_traces(eng, models_mod, group, variant):
         assert st["max_tree_depth"][t] == fx["max_tree_depth"][t]
         assert actions[t] == fx["action_T"][t]
     print(f"fused vs reference: {agree}/{T} traces with identical visit counts and depth sums")
-    assert agree >= 0.8 * T
+    assert agree == T, f"fused vs reference: only {agree}/{T} traces identical (measured on MI355X: all of them)"
 
 
 @pytest.mark.parametrize("group", [4, 16])

@@ -18,7 +18,8 @@ from parity_helpers import (cartpole_model_and_weights, fixture_config, load_gol
 
 pytestmark = pytest.mark.gpu
 
-TRACE_FILES = ["g4_cartpole_traces", "g5_tictactoe_traces", "g5_connect4_traces", "g5_cartpole_ties_traces"]
+TRACE_FILES = ["g4_cartpole_traces", "g5_tictactoe_traces", "g5_connect4_traces", "g5_cartpole_ties_traces",
+               "g5_atari84_traces"]
 EXACT_KEYS = ["noise", "visits", "child_value_sum", "child_prior", "child_reward", "root_value_sum",
               "root_visits", "max_tree_depth", "min_max", "sim_depth", "sim_actions", "sim_ties",
               "child_visits_target", "root_value_target", "action"]
@@ -224,7 +225,26 @@ def test_support_to_scalar_and_softmax_kernels(eng):
 
 
 # ---- native mode: PyTorch-ROCm inference + HIP tree kernels -------------------------------------------
-def native_vs_fixture(eng, model, config, fx, idx, min_agree, value_tol=3e-5, logit_tol=1e-5):
+PARITY_REPORT = {}
+
+
+def _write_parity_report():
+    """Worst deviations per config, for profiles/ (gpurun_out/ is merged back from the GPU box)."""
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
+        json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
+
+
+def native_vs_fixture(eng, model, config, fx, idx, expected_divergent=(), value_tol=3e-5, logit_tol=1e-5, name=None):
+    """Native-mode search (PyTorch-ROCm / HIP inference + HIP tree kernels) of recorded reference traces.
+
+    Every trace must walk the reference's paths simulation for simulation -- except the traces listed in
+    `expected_divergent`, whose fp32 network outputs flip a UCB near-tie on this hardware (measured, MI355X);
+    a trace outside that set that diverges is a regression.  On identical paths every integer statistic, the
+    policy target and the sampled action are exact and the value targets hold `value_tol`."""
     T = len(idx)
     engine = eng.BatchedMCTS(config, T, seeds=[int(fx["seed"][i]) for i in idx])
     engine.set_debug_ties(True)
@@ -235,8 +255,9 @@ def native_vs_fixture(eng, model, config, fx, idx, min_agree, value_tol=3e-5, lo
     paths = np.full((T, S, S), -1, np.int32)
     with torch.no_grad():
         value, reward, policy, hidden = model.initial_inference(torch.from_numpy(obs).cuda())
-        np.testing.assert_allclose(policy.cpu().numpy(), np.stack([fx["root_policy_logits"][i] for i in idx]),
-                                   rtol=logit_tol, atol=logit_tol)
+        want_logits = np.stack([fx["root_policy_logits"][i] for i in idx])
+        worst_logit = float(np.abs(policy.cpu().numpy() - want_logits).max())
+        np.testing.assert_allclose(policy.cpu().numpy(), want_logits, rtol=logit_tol, atol=logit_tol)
         engine.begin_search(legal, to_play, True)
         engine.expand_roots(value, reward.contiguous(), policy, hidden)
         for s in range(S):
@@ -248,54 +269,89 @@ def native_vs_fixture(eng, model, config, fx, idx, min_agree, value_tol=3e-5, lo
     temps = [float(fx["temperature"][i]) for i in idx]
     actions, _ = engine.sample_actions(temps)
     engine.close()
-    same, worst = 0, 0.0
+    same, worst, worst_pred, worst_prior, divergent = 0, 0.0, 0.0, 0.0, {}
     for t, i in enumerate(idx):
         n = int(fx["n_legal"][i])
         assert st["visits"][t].sum() == S and st["root_visits"][t] == S
-        assert abs(st["root_predicted_value"][t] - fx["root_predicted_value"][i]) <= value_tol * max(1, abs(fx["root_predicted_value"][i]))
+        dev = abs(st["root_predicted_value"][t] - fx["root_predicted_value"][i]) / max(1, abs(fx["root_predicted_value"][i]))
+        worst_pred = max(worst_pred, dev)
+        assert dev <= value_tol
         assert np.array_equal(engine.noise[t, :n], fx["noise"][i][:n])          # host RNG: exact
         if not np.array_equal(paths[t], fx["sim_actions"][i][:, :S]):
+            first = int(np.nonzero((paths[t] != fx["sim_actions"][i][:, :S]).any(axis=1))[0][0])
+            divergent[int(i)] = first
             continue
         same += 1
         assert np.array_equal(st["visits"][t], fx["visits"][i])
         assert np.array_equal(cv[t], fx["child_visits_target"][i])              # policy target: exact
         worst = max(worst, abs(rv[t] - fx["root_value_target"][i]) / max(1.0, abs(fx["root_value_target"][i])))
         assert abs(rv[t] - fx["root_value_target"][i]) <= value_tol * max(1.0, abs(fx["root_value_target"][i]))
+        worst_prior = max(worst_prior, float(np.abs(st["child_prior"][t, :n] - fx["child_prior"][i][:n]).max()))
         np.testing.assert_allclose(st["child_prior"][t, :n], fx["child_prior"][i][:n], rtol=0, atol=logit_tol)
         np.testing.assert_allclose(st["child_value_sum"][t, :n], fx["child_value_sum"][i][:n],
                                    rtol=value_tol, atol=value_tol * S)
         assert actions[t] == fx["action_T"][i]
-    print(f"identical-path rate {same}/{T}; worst root-value deviation {worst:.2e} (relative, floor 1)")
-    assert same >= min_agree * T, f"identical-path rate {same}/{T}"
+    print(f"identical-path rate {same}/{T}; worst root-value deviation {worst:.2e} (relative, floor 1); "
+          f"divergent traces (trace: first differing simulation) {divergent}")
+    if name:
+        PARITY_REPORT[name] = dict(traces=T, identical_paths=same, divergent_first_simulation=divergent,
+                                   worst_root_logit_abs=worst_logit, worst_root_predicted_value_rel=worst_pred,
+                                   worst_value_target_rel=worst, worst_prior_abs=worst_prior,
+                                   value_tol=value_tol, logit_tol=logit_tol)
+        _write_parity_report()
+    unexpected = sorted(set(divergent) - set(expected_divergent))
+    assert not unexpected, f"traces {unexpected} left the reference's paths (identical-path rate {same}/{T})"
     return same / T
 
 
-# Residual networks: MIOpen's fp32 convolutions (GPU) and oneDNN's (the reference's CPU run) sum in
-# different orders, so logits agree to ~2e-5 instead of the ~1e-6 of the FC net; the categorical decode
-# (sum of support * softmax over 21 bins) turns that into ~1e-4 on a decoded value.  These are the
-# tolerances used for the ResNet configs; the CartPole config named by the north star keeps 1e-5 / 3e-5.
+# Tolerances per config (BASELINE.md "parity bars"): network logits / priors and decoded values of the recorded
+# reference searches.  CartPole (north-star config) keeps 1e-5 on logits and 3e-5 relative on decoded values
+# (the inverse value transform amplifies one fp32 ulp of the categorical mean ~100x).  The
+# residual networks sum their fp32 convolutions in another order than the reference's oneDNN CPU kernels; the
+# bars below are 2x the worst deviation measured on MI355X (profiles/r02_parity_report.json).
 RESNET_TOL = dict(value_tol=3e-4, logit_tol=5e-5)
+# traces whose search leaves the reference's path on MI355X because an fp32-rounding-sized difference of the
+# network outputs flips a UCB near-tie (trace index: see the report); everything else must match move for move
+EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (), "atari84": ()}
 
 
 def test_native_cartpole_vs_reference(eng, models_mod):
     config = games("cartpole").MuZeroConfig()
     model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
     fx = load_golden("g4_cartpole_traces")
-    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.8)
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), EXPECTED_DIVERGENT["cartpole"],
+                      name="cartpole")
 
 
 def test_native_tictactoe_vs_reference(eng, models_mod):
     config = games("tictactoe").MuZeroConfig()
     model, _ = synthetic_model(models_mod, config, "cuda")
     fx = load_golden("g5_tictactoe_traces")
-    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.7, **RESNET_TOL)
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), EXPECTED_DIVERGENT["tictactoe"],
+                      name="tictactoe", **RESNET_TOL)
 
 
 def test_native_connect4_vs_reference(eng, models_mod):
     config = games("connect4").MuZeroConfig()
     model, _ = synthetic_model(models_mod, config, "cuda")
     fx = load_golden("g5_connect4_traces")
-    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), 0.5, **RESNET_TOL)
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), EXPECTED_DIVERGENT["connect4"],
+                      name="connect4", **RESNET_TOL)
+
+
+def atari84_traces():
+    fx = dict(load_golden("g5_atari84_traces"))
+    fx["obs"] = fx["obs_u8"].astype(np.float32) / np.float32(255)      # 8-bit frames, as recorded
+    return fx
+
+
+def test_native_atari84_vs_reference(eng, models_mod):
+    """BASELINE config #5 end to end: DownsampleCNN representation of 4 x 84 x 84 frames, A = 4, 50 simulations."""
+    config = games("breakout").atari84_config()
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    fx = atari84_traces()
+    native_vs_fixture(eng, model, config, fx, list(range(len(fx["seed"]))), EXPECTED_DIVERGENT["atari84"],
+                      name="atari84", **RESNET_TOL)
 
 
 def test_gpu_network_outputs_vs_reference_fixtures(models_mod):
@@ -408,7 +464,7 @@ def test_mcts_run_facade_matches_reference_trace(eng, models_mod, pkg):
             if child.visit_count > 0:
                 assert child.expanded() and child.hidden_state is not None and child.to_play == 0
     mcts.close()
-    assert hits >= 6
+    assert hits == 8, f"MCTS.run facade: {hits}/8 recorded searches reproduced (measured on MI355X: 8/8)"
     with pytest.raises(AssertionError, match="should not be an empty array"):
         sp.MCTS(config).run(model, fx["obs"][0], [], 0, True)
 
@@ -447,7 +503,7 @@ def test_self_play_games_vs_reference_g6(eng, models_mod, pkg):
                                        atol=RESNET_TOL["value_tol"], equal_nan=True)
             assert int(np.random.randint(0, 2**31 - 1)) == int(fx[f"run{i}_rng_next_word"])
     print(f"games reproduced move for move: {full}/{total}")
-    assert full >= total - 2, f"only {full}/{total} games reproduced move for move"
+    assert full == total, f"only {full}/{total} games reproduced move for move (measured on MI355X: all of them)"
 
 
 def test_batched_self_play_matches_single_env_actor(eng, models_mod, pkg):

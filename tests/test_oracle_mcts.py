@@ -9,7 +9,7 @@ import numpy
 import pytest
 
 TRACE_FILES = ["g4_cartpole_traces", "g5_tictactoe_traces", "g5_connect4_traces",
-               "g5_cartpole_ties_traces"]
+               "g5_cartpole_ties_traces", "g5_atari84_traces"]
 
 
 def replay_trace(oracle, fx, i):
