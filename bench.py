@@ -141,8 +141,8 @@ def launch_ranks(args, argv):
         except subprocess.TimeoutExpired:
             p.kill()
             codes.append(-9)
-    sys.stdout.write(line)
-    sys.stdout.flush()
+    for row in line.splitlines():                           # ONE JSON line on stdout; anything else a rank printed -> stderr
+        print(row, file=sys.stdout if row.startswith("{") else sys.stderr, flush=True)
     bad = [c for c in codes if c != 0]
     return bad[0] if bad else 0
 
@@ -397,6 +397,11 @@ def main(argv=None):
         sys.exit(launch_ranks(args, argv))
     if args.rehearse_cpu:
         return rehearse_cpu(args)
+    cpu_helper = None
+    if args.gpus == 1 and args.cpu_seconds > 0:
+        # the cpu_baseline workers are forked from this helper, which is started before anything here touches the GPU
+        cpu_helper = subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_selfplay.py"), "--serve"],
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
     actor_mod = pkg("actor")
     rank, world, local_rank = actor_mod.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -506,8 +511,8 @@ def main(argv=None):
     if rank == 0:
         if args.profile_steps > 0:
             result["roofline"], result["kernels"] = roofline_leg(wl, args.profile_steps, device)
-        if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline_leg(wl.name, wl.config, args.cpu_seconds, args.cpu_workers)
+        if cpu_helper is not None:
+            result["cpu_baseline"] = cpu_baseline_leg(cpu_helper, wl.name, wl.config, args.cpu_seconds, args.cpu_workers)
             result["speedup_vs_cpu_port_1core"] = value / result["cpu_baseline"]["value"]
             if result["cpu_baseline"].get("all_cores"):
                 result["speedup_vs_cpu_port_all_cores"] = value / result["cpu_baseline"]["all_cores"]["value"]
@@ -515,6 +520,9 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps(result), flush=True)
     wl.close()
+    if cpu_helper is not None:
+        cpu_helper.stdin.close()
+        cpu_helper.wait(timeout=60)
     if world > 1:
         dist.destroy_process_group()
 
@@ -657,7 +665,7 @@ def network_leg(wl, device, repeats=20):
     flops = recurrent_inference_flops(wl.config) * engine.E
     with torch.no_grad():
         if len(engine.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
-            planes = engine.select_planes()
+            planes = engine.batch_planes                     # the dynamics input the last search's gather left behind
             call = lambda: model.recurrent_inference_from_planes(planes, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
         else:
             hidden = engine.batch_hidden.view(engine.E, *engine.state_shape)
@@ -727,29 +735,21 @@ def available_cores():
     return n
 
 
-def cpu_baseline_leg(name, config, seconds, workers=0):
-    """The oracle's port of the reference loop on the host: one core, then one process per available core."""
-    worker = os.path.join(ROOT, "oracle", "cpu_selfplay.py")
-
-    def run(n_procs, secs):
-        t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, worker, name, str(secs), str(i)], stdout=subprocess.PIPE, text=True,
-                                  env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
-                 for i in range(n_procs)]
-        outs = []
-        for p in procs:
-            out, _ = p.communicate(timeout=secs + 600)
-            if p.returncode == 0 and out.strip():
-                outs.append(json.loads(out.strip().splitlines()[-1]))
-        return outs, time.perf_counter() - t0
-
+def cpu_baseline_leg(helper, name, config, seconds, workers=0):
+    """The oracle's port of the reference loop on the host: one core, then one process per available core.  The
+    worker processes belong to `helper` (oracle/cpu_selfplay.py --serve), started before this process opened the GPU."""
     try:
         cpu_model = [line.split(":", 1)[1].strip() for line in open("/proc/cpuinfo") if line.startswith("model name")][0]
     except Exception:
         cpu_model = "unknown"
-    one, _ = run(1, seconds)
+    n = workers or available_cores()
+    if name != "cartpole":
+        n = min(n, 64)                                       # each worker holds a torch runtime (~0.4 GiB)
+    helper.stdin.write(f"{name} {seconds} {n}\n")
+    helper.stdin.flush()
+    answer = json.loads(helper.stdout.readline())
+    one, many, wall = answer["one"], answer["many"], answer["wall"]
     assert one, "cpu_baseline worker failed"
-    one = one[0]
     value = one["sims"] / one["seconds"]
     kind_note = ("tree and FC network in C, one tree at a time" if name == "cartpole" else
                  "tree in C, residual network at batch 1 through torch on the CPU (1 thread), one tree at a time")
@@ -760,17 +760,12 @@ def cpu_baseline_leg(name, config, seconds, workers=0):
     if name in RHO_PORT_OVER_REFERENCE:
         out["rho_port_over_reference_build_container"] = RHO_PORT_OVER_REFERENCE[name]
         out["reference_equivalent_value_extrapolated"] = value / RHO_PORT_OVER_REFERENCE[name]
-    n = workers or available_cores()
-    if name != "cartpole":
-        n = min(n, 64)                                       # each worker holds a torch runtime (~0.4 GiB)
-    if n > 1:
-        many, wall = run(n, seconds)
-        if many:
-            total = sum(o["sims"] / o["seconds"] for o in many)
-            out["all_cores"] = {"value": total, "unit": "simulations/s", "cores": len(many), "kind": "port",
-                                "sample": f"{len(many)} processes x {seconds:.0f} s, one per core, each as the 1-core leg "
-                                          f"(seeds config.seed + worker index, muzero.py:175); wall {wall:.1f} s",
-                                "per_core_value": total / len(many)}
+    if many:
+        total = sum(o["sims"] / o["seconds"] for o in many)
+        out["all_cores"] = {"value": total, "unit": "simulations/s", "cores": len(many), "kind": "port",
+                            "sample": f"{len(many)} processes x {seconds:.0f} s, one per core, each as the 1-core leg "
+                                      f"(seeds config.seed + worker index, muzero.py:175); wall {wall:.1f} s",
+                            "per_core_value": total / len(many)}
     return out
 
 

@@ -333,6 +333,24 @@ int mzmcts_conv_head(const float *x, const mzmcts_head_desc *head, float *out, i
 int mzmcts_conv_heads(const float *x, const mzmcts_head_desc *heads, int32_t n_heads, float *const *outs,
                       int64_t batch, void *stream);
 
+/* ---- 3x3 board convolution on the matrix cores, epilogue fused -------------------------------
+ * out = act( conv3x3(x, weight; padding 1, stride 1, no bias) * scale[c] + shift[c] (+ residual) ): Conv2d ->
+ * BatchNorm2d in eval() -> (+ skip) -> ReLU of the reference's residual networks (models.py:213-229 conv3x3 and
+ * ResidualBlock.forward, 318-330, 399-420) in ONE launch.  Exact fp32 on v_mfma_f32_16x16x4_f32: every output is a
+ * k-ordered fmaf chain over (tap, input channel), i.e. the arithmetic of a scalar fp32 loop.
+ *   x dev f32[batch, cin, height, width] NCHW; out dev f32[batch, cout, height, width] (not x); residual: as out or NULL;
+ *   scale / shift dev f32[cout] (gamma / sqrt(var + eps), beta - mean * scale); relu: 0 = identity;
+ *   packed: the weight [cout, cin, 3, 3] rearranged k-major by mzmcts_board_conv_pack into
+ *   mzmcts_board_conv_packed_floats(cin, cout) floats (repack after every weight change; same buffer, so a
+ *   captured hipGraph follows).  Shapes: mzmcts_board_conv_supported(cin, cout, height, width) != 0
+ *   (boards 3x3, 6x6, 6x7; cout 16 or 64).  No allocation, no synchronisation. */
+int64_t mzmcts_board_conv_packed_floats(int32_t cin, int32_t cout);
+int mzmcts_board_conv_pack(const float *weight, float *packed, int32_t cin, int32_t cout, void *stream);
+int mzmcts_board_conv_supported(int32_t cin, int32_t cout, int32_t height, int32_t width);
+int mzmcts_board_conv3x3(const float *x, const float *packed, const float *scale, const float *shift,
+                         const float *residual, float *out, int64_t batch, int32_t cin, int32_t cout, int32_t height,
+                         int32_t width, int32_t relu, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

@@ -106,6 +106,10 @@ PROTOTYPES = {
     "mzmcts_conv_heads": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void, ctypes.c_int64, c_void]),
     "mzmcts_conv_head": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "mzmcts_unit_rescale": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int32, c_void]),
+    "mzmcts_board_conv_packed_floats": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
+    "mzmcts_board_conv_pack": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, ctypes.c_int32, c_void]),
+    "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
+    "mzmcts_board_conv3x3": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
     "mzenv_advance": (ctypes.c_int, [c_void] * 10),

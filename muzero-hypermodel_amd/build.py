@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
-SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip"]
+SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip", "board_conv.hip"]
 HEADERS = ["np_legacy_rng.h", "tree_layout.h", "tree_device.h", "fc_net_device.h", "narrow_device.h", "kernel_common.h", "env_layout.h", os.path.join("..", "..", "include", "mzmcts.h"),
            os.path.join("..", "..", "include", "mzenv.h"), os.path.join("..", "..", "include", "mzreplay.h"), os.path.join("..", "..", "include", "mzhist.h")]
 
@@ -56,7 +56,7 @@ def build_tools(force=False):
     out_dir = os.path.join(tools, "_bin")
     os.makedirs(out_dir, exist_ok=True)
     built = []
-    for name in ("random_access_ceiling",):
+    for name in ("random_access_ceiling", "record_size_ceiling"):
         src, out = os.path.join(tools, name + ".hip"), os.path.join(out_dir, name)
         if force or not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
             proc = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, src],

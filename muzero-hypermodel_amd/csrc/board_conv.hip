@@ -1,0 +1,313 @@
+// board_conv.hip -- the 3x3 convolution of the board residual networks on the matrix cores (gfx950), with what
+// follows it in the reference fused into the epilogue:
+//
+//     out = act( conv3x3(x, w; padding 1, stride 1, no bias) * scale[c] + shift[c]  (+ residual) )
+//
+// = Conv2d -> BatchNorm2d (eval: running statistics folded into scale / shift) -> (+ x) -> ReLU of
+// reference models.py:213-229 (conv3x3, ResidualBlock.forward), 318-330 (RepresentationNetwork), 399-420
+// (DynamicsNetwork), one launch instead of MIOpen's fp32 Winograd kernel + an element-wise launch.
+//
+// Implicit GEMM, exact fp32:  D[m][n] = sum_k A[m][k] * B[k][n]
+//     m = (sample, y, x) output position      n = output channel      k = (tap, input channel)
+// on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, one rounding per product --
+// the same arithmetic as a scalar fp32 loop over taps and channels).  A workgroup (4 waves) owns SB samples:
+//   * their input goes to LDS once, channel-fastest, as padded planes with a zero border (rows share one zero column), so
+//     a tap is an address offset and the padding needs no predicate; channels are padded to whole groups of 16;
+//   * wave w (8 per workgroup, two per SIMD) owns the 16 output channels of column tile (w % NT) and the row tiles
+//     w / NT, w / NT + 8 / NT, ...; per group of 16 input channels of one tap (4 k-steps) it reads ONE 16-byte value per
+//     row tile from LDS and ONE 16-byte value from the packed weights (global, L2-resident, a group ahead), and issues
+//     4 MFMAs per row tile, each tile into its own accumulator;
+//   * epilogue: accumulators -> LDS tile -> folded batch norm, residual, ReLU -> coalesced NCHW stores.
+// The weights arrive packed by mzmcts_board_conv_pack, refreshed in place whenever the parameters change.
+//
+// Roofline: MFMA-bound by construction (fp32 matrix peak 157.3 TFLOP/s = 64 FLOP/clk/SIMD): Connect4 [1024, 64, 6, 7]
+// -> 3.17 GFLOP per call = 20.2 us at peak; per group a wave issues 24 MFMAs (768 cycles) against 6 LDS reads and one
+// global load.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/mzmcts.h"
+
+namespace mz {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kConvWaves = 8;   // two per SIMD: one wave's LDS reads and weight loads hide under the other's MFMAs
+constexpr int kConvGroup = 16;  // input channels per group = 4 k-steps; a lane fetches its 4 channels with one 16-byte read
+
+__host__ __device__ inline int conv_groups(int cin) { return (cin + kConvGroup - 1) / kConvGroup; }
+__host__ __device__ inline int conv_packed_floats(int cin, int cout) {  // [9 * groups + 1 spare][4 kk][cout][4 g]
+    return (9 * conv_groups(cin) + 1) * 4 * cout * 4;
+}
+
+// Packed weights: wt[(((tap * NG + grp) * 4 + kk) * cout + n) * 4 + g] = w[n][grp * 16 + 4 * kk + g][tap]
+// (0 for channels >= cin and for the spare group): lane (n, kk) of a wave reads the four weights of its four k-steps of
+// a group with ONE 16-byte load, 16 lanes x 16 B contiguous per kk.
+__global__ __launch_bounds__(256) void board_conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin,
+                                                              int cout) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= conv_packed_floats(cin, cout)) return;
+    const int g = i & 3;
+    const int n = (i >> 2) % cout;
+    const int kk = ((i >> 2) / cout) & 3;
+    const int tg = (i >> 2) / cout / 4;                 // tap * NG + grp
+    const int ng = conv_groups(cin);
+    const int tap = tg / ng, grp = tg % ng;
+    const int ci = grp * kConvGroup + 4 * kk + g;
+    wt[i] = (tap < 9 && ci < cin) ? w[(static_cast<size_t>(n) * cin + ci) * 9 + tap] : 0.f;
+}
+
+template <int NT, int H, int W, int SB, bool RESIDUAL, bool RELU>
+__global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const float* __restrict__ x,
+                                                                         const float* __restrict__ wt,
+                                                                         const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift,
+                                                                         const float* __restrict__ residual,
+                                                                         float* __restrict__ out, int batch, int cin) {
+    constexpr int P = H * W;
+    constexpr int PW = W + 1;                           // one zero column between rows: right border of row y = left of y+1
+    constexpr int PP = (H + 2) * PW + 1;                // positions of a padded plane
+    constexpr int ROWS = SB * P;                        // output rows of the workgroup
+    constexpr int MT = (ROWS + 15) / 16;                // row tiles of the workgroup
+    constexpr int RG = kConvWaves / NT;                 // waves sharing a column tile
+    constexpr int MTW = (MT + RG - 1) / RG;             // row tiles per wave
+    constexpr int COUT = 16 * NT;
+    constexpr int LDM = ROWS + 1;                       // row stride of the output staging tile [COUT][LDM]
+    constexpr int THREADS = 64 * kConvWaves;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // planes [SB][PP][CP], later the staging tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b0 = blockIdx.x * SB;
+    const int n_samples = min(SB, batch - b0);
+    const int ng = conv_groups(cin);
+    const int CP = ng * kConvGroup + 4;                 // channel stride (+4 words: rows of a tile fall into different banks)
+
+    // ---- stage the input: zero the LDS tile (borders, padding channels, missing samples), then the boards, channel-
+    //      fastest; global loads 16 bytes per lane, four in flight per thread ------------------------------------------
+    const int count = n_samples * cin * P;              // contiguous in global memory (NCHW)
+    const float* src = x + static_cast<size_t>(b0) * cin * P;
+    {
+        const int words = SB * PP * CP;                 // (CP is a multiple of 4)
+        float4* z = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < words / 4; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    auto place = [&](int i, float v) {
+        const int p = i % P;
+        const int sc = i / P;                           // s * cin + ci
+        const int ci = sc % cin;
+        const int s = sc / cin;
+        lds[(s * PP + (p / W + 1) * PW + (p % W) + 1) * CP + ci] = v;
+    };
+    for (int i0 = tid * 4; i0 < count; i0 += 4 * THREADS * 4) {
+        float4 staged[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * THREADS * 4;
+            staged[k] = (i + 3 < count) ? *reinterpret_cast<const float4*>(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * THREADS * 4;
+            if (i + 3 < count) {
+                place(i, staged[k].x), place(i + 1, staged[k].y), place(i + 2, staged[k].z), place(i + 3, staged[k].w);
+            } else {
+                for (int q = i; q < count; ++q) place(q, src[q]);   // ragged tail (at most 3 floats, one thread)
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane row addresses ---------------------------------------------------------------------------------
+    const int col_tile = wave % NT;
+    const int row_group = wave / NT;
+    const int i_row = lane & 15;
+    const int kk = lane >> 4;                           // this lane feeds channels 4 kk .. 4 kk + 3 of a group
+    int base[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int tile = row_group + t * RG;
+        int m = tile * 16 + i_row;
+        if (tile >= MT || m >= ROWS) m = 0;             // rows past the end read a valid address; never stored
+        const int s = m / P, p = m % P;
+        base[t] = (s * PP + (p / W + 1) * PW + (p % W) + 1) * CP + 4 * kk;
+    }
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- main loop: 9 taps x ng channel groups; per group 4 k-steps (fewer in a short last group) ----------------------
+    // k-step g of a group multiplies channels {4 kk + g : kk = 0..3}: lane (row i, kk) holds A[i][4 kk + g] in element g of
+    // ONE 16-byte LDS read, lane (column n, kk) holds B[4 kk + g][n] in element g of ONE 16-byte global load.  Software
+    // pipeline: the next group's A rows are read while this group's MFMAs issue, the next group's weights are in flight
+    // from L2 meanwhile.
+    const int n_col = col_tile * 16 + i_row;
+    const f32x4* wlane = reinterpret_cast<const f32x4*>(wt) + kk * COUT + n_col;   // + (tap * ng + grp) * 4 * COUT
+    const int last_steps = min(4, cin - (ng - 1) * kConvGroup);                    // k-steps of a tap's last group
+    const int iterations = 9 * ng;
+
+    int grp = 0, tap = 0;                               // the group whose A rows are being fetched
+    auto lds_offset = [&]() { return ((tap / 3 - 1) * PW + (tap % 3 - 1)) * CP + grp * kConvGroup; };
+    auto advance = [&]() {
+        if (++grp == ng) {
+            grp = 0;
+            tap = tap < 8 ? tap + 1 : 8;                // (the read issued in the last iteration is not used)
+        }
+    };
+    f32x4 a[MTW];
+    f32x4 b = wlane[0];
+    {
+        const int off = lds_offset();
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) a[t] = *reinterpret_cast<const f32x4*>(lds + base[t] + off);
+        advance();
+    }
+    int grp_now = 0;
+    for (int it = 0; it < iterations; ++it) {
+        const f32x4 bn = wlane[static_cast<size_t>(it + 1) * 4 * COUT];   // (a spare zero group follows the last one)
+        const int off = lds_offset();
+        f32x4 an[MTW];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) an[t] = *reinterpret_cast<const f32x4*>(lds + base[t] + off);
+        advance();
+        const int steps = (grp_now == ng - 1) ? last_steps : 4;   // uniform
+        grp_now = (grp_now + 1 == ng) ? 0 : grp_now + 1;
+        if (steps == 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+            }
+        } else {                                         // short last group (e.g. the dynamics input's action plane)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                if (g < steps) {
+#pragma unroll
+                    for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) a[t] = an[t];
+        b = bn;
+    }
+
+    // ---- epilogue: accumulators -> LDS tile [column][row] -> folded batch norm, residual, ReLU, coalesced NCHW stores ----
+    const int out_count = n_samples * COUT * P;         // contiguous in global memory; a multiple of 4 (COUT is)
+    const size_t g0 = static_cast<size_t>(b0) * COUT * P;
+    __syncthreads();                                    // every wave has finished reading the planes
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int tile = row_group + t * RG;
+        if (tile >= MT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                   // D[row = 4 * (lane >> 4) + r][col = lane & 15]
+            const int m = tile * 16 + 4 * kk + r;
+            if (m < ROWS) lds[n_col * LDM + m] = acc[t][r];
+        }
+    }
+    __syncthreads();
+    auto finish = [&](int i, float skip) {
+        const int p = i % P;
+        const int sn = i / P;                           // s * COUT + n
+        const int n = sn % COUT;
+        const int s = sn / COUT;
+        float v = lds[n * LDM + s * P + p] * scale[n] + shift[n];
+        if (RESIDUAL) v = v + skip;
+        if (RELU) v = v < 0.f ? 0.f : v;                // (a NaN stays a NaN, as torch.relu keeps it)
+        return v;
+    };
+    for (int i0 = tid * 4; i0 < out_count; i0 += 3 * THREADS * 4) {
+        float4 res[3];
+        if (RESIDUAL) {                                 // three 16-byte loads of the skip connection in flight per thread
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = i0 + k * THREADS * 4;
+                res[k] = i < out_count ? *reinterpret_cast<const float4*>(residual + g0 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = i0 + k * THREADS * 4;
+            if (i < out_count) {
+                const float4 r4 = RESIDUAL ? res[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(out + g0 + i) =
+                    make_float4(finish(i, r4.x), finish(i + 1, r4.y), finish(i + 2, r4.z), finish(i + 3, r4.w));
+            }
+        }
+    }
+}
+
+template <int NT, int H, int W, int SB>
+static int launch_board_conv(const float* x, const float* wt, const float* scale, const float* shift, const float* residual,
+                             float* out, int batch, int cin, int relu, hipStream_t stream) {
+    constexpr int PP = (H + 2) * (W + 1) + 1;
+    const int cp = conv_groups(cin) * kConvGroup + 4;
+    const size_t planes = static_cast<size_t>(SB) * PP * cp;
+    const size_t stage = static_cast<size_t>(16 * NT) * (SB * H * W + 1);
+    const size_t lds = sizeof(float) * std::max(planes, stage);
+    if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
+    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
+#define MZ_CONV_LAUNCH(RES, ACT)                                                                                        \
+    do {                                                                                                                \
+        auto kernel = board_conv3x3_kernel<NT, H, W, SB, RES, ACT>;                                                     \
+        if (lds > 64 * 1024 &&                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                static_cast<int>(lds)) != hipSuccess)                                                   \
+            return MZMCTS_ERR_HIP;                                                                                      \
+        kernel<<<grid, block, lds, stream>>>(x, wt, scale, shift, residual, out, batch, cin);                           \
+    } while (0)
+    if (residual) {
+        if (relu) MZ_CONV_LAUNCH(true, true); else MZ_CONV_LAUNCH(true, false);
+    } else {
+        if (relu) MZ_CONV_LAUNCH(false, true); else MZ_CONV_LAUNCH(false, false);
+    }
+#undef MZ_CONV_LAUNCH
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+}  // namespace mz
+
+extern "C" int64_t mzmcts_board_conv_packed_floats(int32_t cin, int32_t cout) {
+    if (cin <= 0 || cout <= 0) return -1;
+    return mz::conv_packed_floats(cin, cout);
+}
+
+extern "C" int mzmcts_board_conv_pack(const float* weight, float* packed, int32_t cin, int32_t cout, void* stream_) {
+    if (!weight || !packed || cin <= 0 || cout <= 0) return MZMCTS_ERR_INVALID;
+    const int total = mz::conv_packed_floats(cin, cout);
+    mz::board_conv_pack_kernel<<<dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_)>>>(weight, packed,
+                                                                                                             cin, cout);
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+extern "C" int mzmcts_board_conv_supported(int32_t cin, int32_t cout, int32_t height, int32_t width) {
+    const bool shape = (height == 6 && width == 7) || (height == 6 && width == 6) || (height == 3 && width == 3);
+    return shape && (cout == 64 || cout == 16) && cin >= 1 && cin <= 80 ? 1 : 0;
+}
+
+extern "C" int mzmcts_board_conv3x3(const float* x, const float* packed, const float* scale, const float* shift,
+                                    const float* residual, float* out, int64_t batch, int32_t cin, int32_t cout,
+                                    int32_t height, int32_t width, int32_t relu, void* stream_) {
+    if (!x || !packed || !scale || !shift || !out || batch < 0 || batch > 0x3fffffff ||
+        !mzmcts_board_conv_supported(cin, cout, height, width) || out == x)
+        return MZMCTS_ERR_INVALID;
+    if (batch == 0) return MZMCTS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int b = static_cast<int>(batch);
+    // samples per workgroup: 8 waves x <= 6 row tiles each, planes within LDS
+    if (height == 6 && width == 7) {
+        if (cout == 64) return mz::launch_board_conv<4, 6, 7, 4>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+        return mz::launch_board_conv<1, 6, 7, 8>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+    }
+    if (height == 6 && width == 6) {
+        if (cout == 64) return mz::launch_board_conv<4, 6, 6, 4>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+        return mz::launch_board_conv<1, 6, 6, 16>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+    }
+    if (cout == 64) return mz::launch_board_conv<4, 3, 3, 16>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+    return mz::launch_board_conv<1, 3, 3, 32>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+}

@@ -41,7 +41,9 @@ class BaseMuZeroConfig:
         for key, value in {**DEFAULTS, **self.OVERRIDES}.items():
             setattr(self, key, copy.deepcopy(value))
         if self.train_on_gpu is None:
-            self.train_on_gpu = torch.cuda.is_available()
+            # (the reference asks torch.cuda.is_available(); counting devices gives the same answer without
+            # initialising the GPU, which a config object built in a CPU-only helper process must not do)
+            self.train_on_gpu = torch.cuda.device_count() > 0
         self.results_path = os.path.join(
             os.path.dirname(os.path.realpath(__file__)), "../results", self.GAME,
             datetime.datetime.now().strftime("%Y-%m-%d--%H-%M-%S"))

@@ -16,6 +16,7 @@ Differences that matter on the GPU hot path (values are unchanged):
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -349,6 +350,57 @@ class BoardConv2d(torch.nn.Conv2d):
     broadcast into aliased storage."""
     DENSE_MAX_ELEMENTS = 1 << 19   # of the expanded matrix (2 MB): 16 channels on 6x6 yes, 64 channels on 6x7 no
 
+    # ---- matrix-core path (include/mzmcts.h mzmcts_board_conv3x3) ----------------------------------------------
+    def takes_mfma_path(self, x):
+        """Inference on the GPU on a board the HIP implicit-GEMM kernel covers (and the dense GEMM does not)."""
+        mode = os.environ.get("MZ_BOARD_CONV", "auto")      # auto | all (also where the dense GEMM applies) | off
+        if mode == "off" or self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 \
+                or x.dim() != 4 or self.stride != (1, 1) or self.kernel_size != (3, 3):
+            return False
+        if mode != "all" and self.takes_dense_path(x):
+            return False
+        return bool(_native.load().mzmcts_board_conv_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3]))
+
+    def packed(self):
+        """The weight rearranged k-major for the kernel; same buffer for the module's lifetime (a captured hipGraph
+        keeps reading it), refilled when the weight changes (version counter) or on refold()."""
+        lib = _native.load()
+        buf = self.__dict__.get("_packed")
+        if buf is None or buf.device != self.weight.device:
+            n = lib.mzmcts_board_conv_packed_floats(self.in_channels, self.out_channels)
+            buf = self.__dict__["_packed"] = torch.empty(n, dtype=torch.float32, device=self.weight.device)
+            self._packed_version = None
+        if getattr(self, "_packed_version", None) != self._dense_key():
+            self._repack()
+        return buf
+
+    def _repack(self):
+        buf = self.__dict__["_packed"]
+        with torch.cuda.device(buf.device):
+            rc = _native.load().mzmcts_board_conv_pack(self.weight.data_ptr(), buf.data_ptr(), self.in_channels,
+                                                       self.out_channels, torch.cuda.current_stream(buf.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mzmcts_board_conv_pack failed ({rc})")
+        self._packed_version = self._dense_key()
+
+    def fused(self, x, bn, residual=None, relu=True):
+        """relu(bn(conv(x)) [+ residual]) in one launch on the matrix cores."""
+        scale, shift = bn.folded()
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        b, _, h, w = x.shape
+        out = torch.empty((b, self.out_channels, h, w), dtype=torch.float32, device=x.device)
+        packed = self.packed()
+        with torch.cuda.device(x.device):
+            rc = _native.load().mzmcts_board_conv3x3(
+                x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                residual.data_ptr() if residual is not None else None, out.data_ptr(), b, self.in_channels,
+                self.out_channels, h, w, 1 if relu else 0, torch.cuda.current_stream(x.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mzmcts_board_conv3x3 failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+        return out
+
     def _expansion(self, h, w, device):
         """(index into weight.flatten(), 0/1 mask), both [c_in*h*w, c_out*h*w]: entry ((ci,y',x'), (co,y,x)) takes
         weight[co, ci, y'-y+1, x'-x+1] when that tap exists."""
@@ -375,6 +427,8 @@ class BoardConv2d(torch.nn.Conv2d):
     def refold(self):
         """Rebuild every cached expanded matrix from the current weight (and the batch norms folded into some of
         them), in place."""
+        if self.__dict__.get("_packed") is not None:
+            self._repack()
         with torch.no_grad():
             for (h, w, _), matrix in self.__dict__.get("_dense", {}).items():
                 index, mask = self._expansion(h, w, self.weight.device)
@@ -435,6 +489,8 @@ class BoardConv2d(torch.nn.Conv2d):
 def conv_bn_relu(conv, bn, x):
     """relu(bn(conv(x))) (reference models.py:215-225, 318-330).  On the dense small-board path in inference: ONE
     GEMM -- batch-norm scale folded into the expanded matrix, shift and ReLU in the GEMM's epilogue."""
+    if isinstance(conv, BoardConv2d) and not bn.training and conv.takes_mfma_path(x):
+        return conv.fused(x, bn)
     if isinstance(conv, BoardConv2d) and conv.takes_dense_path(x) and not bn.training:
         b, _, h, w = x.shape
         matrix, bias = conv.dense_with(bn, h, w)
@@ -456,6 +512,8 @@ class ResidualBlock(torch.nn.Module):
 
     def forward(self, x):
         y = conv_bn_relu(self.conv1, self.bn1, x)
+        if not self.bn2.training and self.conv2.takes_mfma_path(y):
+            return self.conv2.fused(y, self.bn2, residual=x)
         return conv_epilogue(self.conv2(y), self.bn2, residual=x)
 
 

@@ -12,7 +12,12 @@ through the oracle's C restatement (oracle/mz_oracle.c) for a bounded number of 
 
     python oracle/cpu_selfplay.py <workload> <seconds> [seed]      -> one JSON line {"sims", "moves", "seconds"}
 
-bench.py runs one of these for the 1-core figure and one per available host core for the all-cores figure.
+    python oracle/cpu_selfplay.py --serve       -> reads "<workload> <seconds> <workers>" lines on stdin and answers
+                                                   each with one JSON line {"one": {...}, "many": [{...}, ...], "wall": s}
+
+bench.py starts the `--serve` form BEFORE it touches the GPU and asks it for the two legs (1 core, one process per
+available core) after the GPU measurements: every worker is then forked from a process that never held the GPU (a
+GPU box allows only a few processes with the device open, and a fork of the benchmark process would count).
 """
 import importlib
 import json
@@ -130,5 +135,34 @@ def run(name, seconds, seed=0):
     return run_cartpole(seconds, seed) if name == "cartpole" else run_residual(name, seconds, seed)
 
 
+def _spawn(name, seconds, n):
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="",
+               ROCR_VISIBLE_DEVICES="")                     # CPU work only: never open the GPU
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), name, str(seconds), str(i)],
+                              stdout=subprocess.PIPE, text=True, env=env) for i in range(n)]
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds + 600)
+        if p.returncode == 0 and out.strip():
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+    return outs, time.perf_counter() - t0
+
+
+def serve():
+    for line in sys.stdin:
+        parts = line.split()
+        if not parts:
+            continue
+        name, seconds, workers = parts[0], float(parts[1]), int(parts[2])
+        one, _ = _spawn(name, seconds, 1)
+        many, wall = _spawn(name, seconds, workers) if workers > 1 else ([], 0.0)
+        print(json.dumps({"one": one[0] if one else None, "many": many, "wall": wall}), flush=True)
+
+
 if __name__ == "__main__":
-    print(json.dumps(run(sys.argv[1], float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)))
+    if sys.argv[1] == "--serve":
+        serve()
+    else:
+        print(json.dumps(run(sys.argv[1], float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)))

@@ -1,0 +1,125 @@
+"""include/mzmcts.h mzmcts_board_conv3x3 -- the residual networks' 3x3 convolution + BatchNorm2d (eval) + skip + ReLU
+as one launch on the matrix cores (csrc/board_conv.hip; reference models.py:213-229, 318-330, 399-420) -- against:
+
+  * integer-valued inputs and weights, where every product and partial sum is exact in fp32: the kernel must equal the
+    integer convolution EXACTLY whatever the summation order (catches any tile / lane / tap / channel mix-up);
+  * an fp64 convolution on random data, within the error of one fp32 fmaf chain over K = 9 * cin terms;
+  * the module path it replaces (torch convolution + mzmcts_affine_act) on the residual block and on a whole Connect4
+    network, within fp32 rounding of the different summation orders.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # batch, cin, cout, h, w -- every kernel instantiation, ragged batches, padded channel counts
+    (37, 64, 64, 6, 7), (1024, 65, 64, 6, 7), (3, 3, 64, 6, 7), (9, 16, 16, 6, 7), (50, 17, 16, 6, 6), (21, 16, 16, 6, 6),
+    (7, 64, 64, 6, 6), (130, 17, 16, 3, 3), (64, 16, 16, 3, 3), (33, 64, 64, 3, 3), (1, 16, 16, 3, 3),
+]
+
+
+def _call(lib, x, weight, scale, shift, residual, relu):
+    b, cin, h, w = x.shape
+    cout = weight.shape[0]
+    packed = torch.empty(lib.mzmcts_board_conv_packed_floats(cin, cout), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.mzmcts_board_conv_pack(weight.data_ptr(), packed.data_ptr(), cin, cout, stream) == 0
+    out = torch.full((b, cout, h, w), float("nan"), device="cuda")
+    rc = lib.mzmcts_board_conv3x3(x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                  residual.data_ptr() if residual is not None else None, out.data_ptr(), b, cin, cout, h, w,
+                                  1 if relu else 0, stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
+    return importlib.import_module("muzero-hypermodel_amd._native").load()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_integer_data_is_exact(lib, shape):
+    b, cin, cout, h, w = shape
+    assert lib.mzmcts_board_conv_supported(cin, cout, h, w)
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(-3, 4, (b, cin, h, w), generator=g).float().cuda()
+    weight = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float().cuda()      # asymmetric in every index
+    scale = torch.randint(1, 4, (cout,), generator=g).float().cuda()
+    shift = torch.randint(-5, 6, (cout,), generator=g).float().cuda()
+    residual = torch.randint(-4, 5, (b, cout, h, w), generator=g).float().cuda()
+    conv = torch.nn.functional.conv2d(x.double().cpu(), weight.double().cpu(), padding=1)
+    for res, relu in ((None, True), (residual, True), (residual, False), (None, False)):
+        want = conv * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+        if res is not None:
+            want = want + res.double().cpu()
+        if relu:
+            want = want.clamp_min(0)
+        got = _call(lib, x, weight, scale, shift, res, relu)
+        assert np.array_equal(got.cpu().numpy(), want.float().numpy()), (shape, res is not None, relu)
+
+
+@pytest.mark.parametrize("shape", [(1024, 64, 64, 6, 7), (300, 65, 64, 6, 7), (4096, 16, 16, 3, 3), (512, 17, 16, 6, 6)])
+def test_random_data_within_one_fp32_chain_of_fp64(lib, shape):
+    b, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((b, cin, h, w), generator=g).cuda()
+    weight = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
+    one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    got = _call(lib, x, weight, one, zero, None, False).double().cpu()
+    want = torch.nn.functional.conv2d(x.double().cpu(), weight.double().cpu(), padding=1)
+    magnitude = torch.nn.functional.conv2d(x.abs().double().cpu(), weight.abs().double().cpu(), padding=1)   # sum |a b|
+    # a k-ordered fp32 fmaf chain: |error| <= ~K eps sum|a b| worst case, ~sqrt(K) eps typically (guide: 0.75-1.5e-7 sum|a b|)
+    assert float(((got - want).abs() / magnitude).max()) < 4e-7
+    # NaN / inf propagate like any fp32 arithmetic
+    x[0, 0, 1, 1] = float("nan")
+    got = _call(lib, x, weight, one, zero, None, True)
+    assert torch.isnan(got[0, :, 0:3, 0:3]).all() and not torch.isnan(got[1:]).any()
+
+
+def test_rejects_what_it_does_not_cover(lib):
+    assert not lib.mzmcts_board_conv_supported(64, 32, 6, 7) and not lib.mzmcts_board_conv_supported(64, 64, 8, 8)
+    x = torch.zeros(2, 64, 8, 8, device="cuda")
+    out = torch.zeros(2, 64, 8, 8, device="cuda")
+    s = torch.zeros(64, device="cuda")
+    rc = lib.mzmcts_board_conv3x3(x.data_ptr(), x.data_ptr(), s.data_ptr(), s.data_ptr(), None, out.data_ptr(), 2, 64, 64, 8, 8,
+                                  1, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0
+
+
+def test_residual_block_and_connect4_network_follow_the_torch_path(pkg, monkeypatch):
+    """The modules route Connect4-sized boards through the kernel; the torch convolution + affine_act path they took
+    before gives the same numbers to fp32 rounding, and a weight refresh is seen (packed weights refilled in place)."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.connect4").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda")
+    g = torch.Generator().manual_seed(3)
+    obs = torch.randint(0, 2, (96, 3, 6, 7), generator=g).float().cuda()
+    action = torch.randint(0, 7, (96, 1), generator=g).cuda()
+    block = model.prediction_network.module.resblocks[0]
+    with torch.no_grad():
+        assert block.conv1.takes_mfma_path(torch.zeros(4, 64, 6, 7, device="cuda"))
+        fused = model.recurrent_inference(model.initial_inference(obs)[3], action)
+        packed_ptr = block.conv1.packed().data_ptr()
+        monkeypatch.setenv("MZ_BOARD_CONV", "off")
+        assert not block.conv1.takes_mfma_path(torch.zeros(4, 64, 6, 7, device="cuda"))
+        plain = model.recurrent_inference(model.initial_inference(obs)[3], action)
+        monkeypatch.setenv("MZ_BOARD_CONV", "auto")
+        for a, b in zip(fused, plain):                     # (the hidden state is min-max rescaled: small spans amplify)
+            torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5)
+        # weight refresh behind the module's back (what a broadcast into the flat buffer does)
+        block.conv1.weight.data.mul_(0.5)
+        model.refresh_inference_constants()
+        assert block.conv1.packed().data_ptr() == packed_ptr
+        after = model.recurrent_inference(model.initial_inference(obs)[3], action)
+        monkeypatch.setenv("MZ_BOARD_CONV", "off")
+        plain_after = model.recurrent_inference(model.initial_inference(obs)[3], action)
+    assert not torch.allclose(after[0], fused[0])
+    for a, b in zip(after, plain_after):
+        torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5)

@@ -312,7 +312,8 @@ def native_vs_fixture(eng, model, config, fx, idx, expected_divergent=(), value_
 RESNET_TOL = dict(value_tol=3e-4, logit_tol=5e-5)
 # traces whose search leaves the reference's path on MI355X because an fp32-rounding-sized difference of the
 # network outputs flips a UCB near-tie (trace index: see the report); everything else must match move for move
-EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (), "atari84": ()}
+# connect4: traces 21 and 23 leave the reference's path at simulation 146 / 167 of 200 (28/30 identical)
+EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (21, 23), "atari84": ()}
 
 
 def test_native_cartpole_vs_reference(eng, models_mod):

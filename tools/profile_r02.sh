@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-2 measurement recipes.  Run on the GPU box from the repo root:   bash tools/profile_r02.sh <what>
+#   bench4     the four driver-runnable bench lines + the --gpus 2 self-launch rehearsal  -> gpurun_out/bench_<w>.json
+#   stats      rocprofv3 --kernel-trace --stats of each workload's bench command        -> gpurun_out/<w>_kernel_stats.csv
+#   fusedsq    SQ-counter passes of the fused CartPole kernel (2 passes x 8 counters)    -> gpurun_out/fused_sq.json
+#   traffic    FETCH_SIZE / WRITE_SIZE passes of the fused CartPole bench                -> gpurun_out/pmc_traffic_e4096.json
+# (the program goes directly after `--`; counters are collected in their own runs, with --kernel-trace only)
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$R/gpurun_out"
+what=${1:-bench4}
+PY=python3
+case "$what" in
+bench4)
+    cd "$R"
+    for w in cartpole tictactoe connect4 atari84; do
+        steps=100; [ $w = connect4 ] && steps=10; [ $w = atari84 ] && steps=20; [ $w = tictactoe ] && steps=40
+        timeout -k 10 900 $PY bench.py --workload $w --steps $steps --warmup 3 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
+        tail -c 400 gpurun_out/bench_$w.json; echo
+    done
+    timeout -k 10 300 $PY bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/bench_gpus2_rehearsal.json 2> gpurun_out/bench_gpus2_rehearsal.err
+    tail -c 600 gpurun_out/bench_gpus2_rehearsal.json; echo
+    ;;
+stats)
+    cd /tmp && export TMPDIR=/tmp
+    for w in cartpole tictactoe connect4 atari84; do
+        steps=20; [ $w = connect4 ] && steps=2; [ $w = atari84 ] && steps=4; [ $w = tictactoe ] && steps=8
+        timeout -k 10 600 rocprofv3 --kernel-trace --stats -d /tmp/ks_$w -o $w --output-format csv -- \
+            $PY "$R/bench.py" --workload $w --steps $steps --warmup 2 --min-seconds 0 --cpu-seconds 0 > "$R/gpurun_out/ks_$w.log" 2>&1
+        cp "$(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1)" "$R/gpurun_out/${w}_kernel_stats.csv"
+    done
+    ;;
+fusedsq)
+    cd /tmp && export TMPDIR=/tmp
+    timeout -k 10 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM \
+        --kernel-trace -d /tmp/sq_a -o a --output-format csv -- \
+        $PY "$R/bench.py" --steps 20 --warmup 5 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 > "$R/gpurun_out/sq_a.log" 2>&1
+    timeout -k 10 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
+        --kernel-trace -d /tmp/sq_b -o b --output-format csv -- \
+        $PY "$R/bench.py" --steps 20 --warmup 5 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 > "$R/gpurun_out/sq_b.log" 2>&1
+    $PY "$R/tools/pmc_summary.py" /tmp/sq_a --sq 50 --top 4 > "$R/gpurun_out/fused_sq_insts.json"
+    $PY "$R/tools/pmc_summary.py" /tmp/sq_b --sq 50 --top 4 > "$R/gpurun_out/fused_sq_waits.json"
+    ;;
+traffic)
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace -d /tmp/tr_$c -o t --output-format csv -- \
+            $PY "$R/bench.py" --steps 20 --warmup 5 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 > "$R/gpurun_out/tr_$c.log" 2>&1
+        $PY "$R/tools/pmc_summary.py" /tmp/tr_$c --top 6 > "$R/gpurun_out/traffic_$c.json"
+    done
+    ;;
+esac
