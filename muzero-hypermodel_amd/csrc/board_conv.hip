@@ -38,8 +38,8 @@ constexpr int kConvWaves = 8;   // two per SIMD: one wave's LDS reads and weight
 constexpr int kConvGroup = 16;  // input channels per group = 4 k-steps; a lane fetches its 4 channels with one 16-byte read
 
 __host__ __device__ inline int conv_groups(int cin) { return (cin + kConvGroup - 1) / kConvGroup; }
-__host__ __device__ inline int conv_packed_floats(int cin, int cout) {  // [9 * groups + 1 spare][4 kk][cout][4 g]
-    return (9 * conv_groups(cin) + 1) * 4 * cout * 4;
+__host__ __device__ inline int conv_packed_floats(int cin, int cout) {  // [9 * groups + 2 spare][4 kk][cout][4 g]
+    return (9 * conv_groups(cin) + 2) * 4 * cout * 4;
 }
 
 // Packed weights: wt[(((tap * NG + grp) * 4 + kk) * cout + n) * 4 + g] = w[n][grp * 16 + 4 * kk + g][tap]
@@ -60,12 +60,12 @@ __global__ __launch_bounds__(256) void board_conv_pack_kernel(const float* __res
 }
 
 template <int NT, int H, int W, int SB, bool RESIDUAL, bool RELU>
-__global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * kConvWaves) void board_conv3x3_kernel(const float* __restrict__ x,
                                                                          const float* __restrict__ wt,
                                                                          const float* __restrict__ scale,
                                                                          const float* __restrict__ shift,
                                                                          const float* __restrict__ residual,
-                                                                         float* __restrict__ out, int batch, int cin) {
+                                                                         float* __restrict__ out, int batch, int cin, uint32_t cin_magic) {
     constexpr int P = H * W;
     constexpr int PW = W + 1;                           // one zero column between rows: right border of row y = left of y+1
     constexpr int PP = (H + 2) * PW + 1;                // positions of a padded plane
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const
     auto place = [&](int i, float v) {
         const int p = i % P;
         const int sc = i / P;                           // s * cin + ci
-        const int ci = sc % cin;
-        const int s = sc / cin;
+        const int s = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin_magic));   // sc / cin (sc < 2^16: exact)
+        const int ci = sc - s * cin;
         lds[(s * PP + (p / W + 1) * PW + (p % W) + 1) * CP + ci] = v;
     };
     for (int i0 = tid * 4; i0 < count; i0 += 4 * THREADS * 4) {
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const
     };
     f32x4 a[MTW];
     f32x4 b = wlane[0];
+    f32x4 b1 = wlane[4 * COUT];                         // weights stay two groups ahead of the MFMAs (L2 round trip)
     {
         const int off = lds_offset();
 #pragma unroll
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const
     }
     int grp_now = 0;
     for (int it = 0; it < iterations; ++it) {
-        const f32x4 bn = wlane[static_cast<size_t>(it + 1) * 4 * COUT];   // (a spare zero group follows the last one)
+        const f32x4 bn = wlane[static_cast<size_t>(it + 2) * 4 * COUT];   // (two spare zero groups follow the last one)
         const int off = lds_offset();
         f32x4 an[MTW];
 #pragma unroll
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const
         }
 #pragma unroll
         for (int t = 0; t < MTW; ++t) a[t] = an[t];
-        b = bn;
+        b = b1;
+        b1 = bn;
     }
 
     // ---- epilogue: accumulators -> LDS tile [column][row] -> folded batch norm, residual, ReLU, coalesced NCHW stores ----
@@ -210,13 +212,16 @@ __global__ __launch_bounds__(64 * kConvWaves, 4) void board_conv3x3_kernel(const
             if (m < ROWS) lds[n_col * LDM + m] = acc[t][r];
         }
     }
+    float* affine = lds + COUT * LDM;                   // [scale | shift] behind the tile
+    if (tid < COUT) affine[tid] = scale[tid];
+    else if (tid < 2 * COUT) affine[tid] = shift[tid - COUT];
     __syncthreads();
     auto finish = [&](int i, float skip) {
         const int p = i % P;
         const int sn = i / P;                           // s * COUT + n
         const int n = sn % COUT;
         const int s = sn / COUT;
-        float v = lds[n * LDM + s * P + p] * scale[n] + shift[n];
+        float v = lds[n * LDM + s * P + p] * affine[n] + affine[COUT + n];
         if (RESIDUAL) v = v + skip;
         if (RELU) v = v < 0.f ? 0.f : v;                // (a NaN stays a NaN, as torch.relu keeps it)
         return v;
@@ -248,7 +253,7 @@ static int launch_board_conv(const float* x, const float* wt, const float* scale
     constexpr int PP = (H + 2) * (W + 1) + 1;
     const int cp = conv_groups(cin) * kConvGroup + 4;
     const size_t planes = static_cast<size_t>(SB) * PP * cp;
-    const size_t stage = static_cast<size_t>(16 * NT) * (SB * H * W + 1);
+    const size_t stage = static_cast<size_t>(16 * NT) * (SB * H * W + 1) + 2 * 16 * NT;
     const size_t lds = sizeof(float) * std::max(planes, stage);
     if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
     const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
@@ -259,7 +264,7 @@ static int launch_board_conv(const float* x, const float* wt, const float* scale
             hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 static_cast<int>(lds)) != hipSuccess)                                                   \
             return MZMCTS_ERR_HIP;                                                                                      \
-        kernel<<<grid, block, lds, stream>>>(x, wt, scale, shift, residual, out, batch, cin);                           \
+        kernel<<<grid, block, lds, stream>>>(x, wt, scale, shift, residual, out, batch, cin, 0xFFFFFFFFu / static_cast<uint32_t>(cin) + 1u);                           \
     } while (0)
     if (residual) {
         if (relu) MZ_CONV_LAUNCH(true, true); else MZ_CONV_LAUNCH(true, false);
