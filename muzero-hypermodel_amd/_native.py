@@ -282,3 +282,13 @@ class HostRng:
         key = np.ascontiguousarray(state[1], dtype=np.uint32)
         self._lib.mzmcts_rng_import(self._h, ptr(key, c_u32_p), int(state[2]), int(state[3]),
                                     float(state[4]))
+
+
+def exact_inverse_temperature(temperature):
+    """k when 1 / temperature is an integer k in 1..4 (the temperatures the device sampler handles exactly:
+    csrc/kernel_common.h exact_inverse_temperature), else 0."""
+    if temperature in (0, float("inf")) or temperature != temperature:
+        return 0
+    inv = 1.0 / float(temperature)
+    k = int(inv)
+    return k if inv == k and 1 <= k <= 4 else 0

@@ -427,7 +427,127 @@ class MinMaxStats:
         return value
 
 
-class BatchedSelfPlay:
+class ManyEnvLoop:
+    """`continuous_self_play` for the many-env actors (BatchedSelfPlay, DeviceSelfPlay): the reference's loop
+    (self_play.py:31-108) with one actor playing E games at once.
+
+    One pass of the loop = the reference's pass for one game, in the same order of storage calls:
+        loop condition   get_info("training_step"), get_info("terminate")
+        weight pull      get_info("weights") -> set_weights           (self_play.py:37: before every game)
+        training         temperature = visit_softmax_temperature_fn(get_info("training_step")), play until at
+                         least one env finishes a game, replay_buffer.save_game(history, shared_storage) per game
+        test mode        temperature 0; per finished game set_info({episode_length, total_reward, mean_value})
+                         (+ {muzero_reward, opponent_reward} for two players)
+        throttle         self_play_delay sleep, then the training_step / num_played_steps < ratio wait
+    so with E == 1 the call sequence is the reference's own (fixture G15, tests/test_self_play_loop.py).  With E > 1
+    every env that starts a game after a pull plays it with the pulled weights; envs in mid-game switch to them at
+    that move boundary, and every game records the weight version (the training step of the
+    pull) it started and ended with in `weights_version`.
+
+    `moves_per_pass`: play exactly that many moves per pass instead of "until a game ends" -- required when the
+    actors of several GPUs run this loop together (torch.distributed initialised): every rank then makes the same
+    collective calls.  Rank 0 alone talks to `shared_storage`; the loop condition travels as a 2-word broadcast and
+    the weights as one broadcast of the flat buffer (weights.FlatWeights, RCCL over xGMI) when their version moved."""
+
+    def _loop_state(self):
+        st = self.__dict__.get("_loop")
+        if st is None:
+            st = self.__dict__["_loop"] = dict(version=0, started=numpy.zeros(self.E, dtype=numpy.int64), flat=None)
+        return st
+
+    def _distributed(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _loop_control(self, shared_storage, training_steps):
+        """(training_step, terminate) as every rank must see them."""
+        if not self._distributed():
+            step = shared_storage.get_info("training_step")
+            return step, (step >= training_steps or shared_storage.get_info("terminate"))
+        import torch.distributed as dist
+        word = torch.zeros(2, dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        if dist.get_rank() == 0:
+            step = shared_storage.get_info("training_step")
+            word[0], word[1] = int(step), int(step >= training_steps or bool(shared_storage.get_info("terminate")))
+        dist.broadcast(word, src=0)
+        return int(word[0]), bool(word[1])
+
+    def _pull_weights(self, shared_storage, version):
+        st = self._loop_state()
+        if not self._distributed():
+            self.set_weights(shared_storage.get_info("weights"))
+        else:
+            import torch.distributed as dist
+            from .weights import FlatWeights
+            if st["flat"] is None:
+                st["flat"] = FlatWeights(self.model)
+            if dist.get_rank() == 0:
+                st["flat"].load_state_dict(shared_storage.get_info("weights"))
+            st["flat"].broadcast(src=0)
+        st["version"] = int(version)
+
+    def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
+        """Play until a game ends (moves_per_pass None) or exactly moves_per_pass moves; returns the finished games
+        as (env index, GameHistory) pairs in the order they ended."""
+        finished = []
+        moves = 0
+        while True:
+            self.step(temperature, temperature_threshold, on_game=lambda e, gh: finished.append((e, gh)))
+            moves += 1
+            if (moves_per_pass is None and finished) or (moves_per_pass is not None and moves >= moves_per_pass):
+                return finished
+
+    def continuous_self_play(self, shared_storage, replay_buffer, test_mode=False, moves_per_pass=None):
+        cfg = self.config
+        st = self._loop_state()
+        if self._distributed() and moves_per_pass is None:
+            raise ValueError("several ranks: give moves_per_pass so that every rank makes the same collective calls")
+        if test_mode and len(cfg.players) > 1 and cfg.opponent != "self":
+            raise NotImplementedError("many-env test mode plays \"self\"; use SelfPlay for expert / random opponents")
+        talker = not self._distributed() or torch.distributed.get_rank() == 0
+        while True:
+            step, stop = self._loop_control(shared_storage, cfg.training_steps)
+            if stop:
+                break
+            self._pull_weights(shared_storage, step)
+            if not test_mode:
+                temperature = cfg.visit_softmax_temperature_fn(
+                    trained_steps=shared_storage.get_info("training_step") if talker else step)
+            else:
+                temperature = 0                          # best action, no exploration noise in the sampling
+            finished = self._play_pass(temperature, cfg.temperature_threshold, moves_per_pass)
+            for e, game_history in finished:
+                game_history.weights_version = (int(st["started"][e]), st["version"])
+                st["started"][e] = st["version"]
+                if not test_mode:
+                    replay_buffer.save_game(game_history, shared_storage)
+                elif talker:
+                    shared_storage.set_info({
+                        "episode_length": len(game_history.action_history) - 1,
+                        "total_reward": sum(game_history.reward_history),
+                        "mean_value": numpy.mean([value for value in game_history.root_values if value]),
+                    })
+                    if 1 < len(cfg.players):
+                        mine = cfg.muzero_player
+                        shared_storage.set_info({
+                            "muzero_reward": sum(reward for i, reward in enumerate(game_history.reward_history)
+                                                 if game_history.to_play_history[i - 1] == mine),
+                            "opponent_reward": sum(reward for i, reward in enumerate(game_history.reward_history)
+                                                   if game_history.to_play_history[i - 1] != mine),
+                        })
+            # Managing the self-play / training ratio (self_play.py:92-106)
+            if not test_mode and cfg.self_play_delay:
+                time.sleep(cfg.self_play_delay)
+            if not test_mode and cfg.ratio and talker:
+                while (shared_storage.get_info("training_step")
+                       / max(1, shared_storage.get_info("num_played_steps")) < cfg.ratio
+                       and shared_storage.get_info("training_step") < cfg.training_steps
+                       and not shared_storage.get_info("terminate")):
+                    time.sleep(0.5)
+        self.close()
+
+
+class BatchedSelfPlay(ManyEnvLoop):
     """E games in lock step on one GPU: the MI355X-native actor.
 
     Env e plays with `Game(seed + e)` and the RNG stream of reference worker `seed + e`
@@ -648,7 +768,7 @@ class HistoryFiler:
                            root_values=arr(ptrs[7], ct.c_double, (count, W)))
 
 
-class DeviceSelfPlay:
+class DeviceSelfPlay(ManyEnvLoop):
     """Self-play with device-resident environments (games.device.DeviceEnvs): search, env step and
     observation all stay on the GPU; per move the host only draws the exploration noise, samples the
     actions (both on the per-env numpy-compatible RNG streams) and files the move into packed per-env
@@ -708,8 +828,8 @@ class DeviceSelfPlay:
 
     def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
         """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
+        self.flush(on_game, on_games)      # first: the unfiled batch holds views of the download ring
         self._drop_batch()
-        self.flush(on_game, on_games)
         if getattr(self, "_filer_owns_rows", False):
             self._filer.store_rows(self._obs, self._act, self._rew, self._tp, self._cv, self._rv, self._len)
             self._filer_owns_rows = False
@@ -773,6 +893,10 @@ class DeviceSelfPlay:
         Needs a game whose legal action set never changes (CartPole) and a fully-connected network.
         An env may come back with fewer than n_moves moves played (it plays the rest next time)."""
         E, eng, envs, cfg = self.E, self.engine, self.envs, self.config
+        if cfg.temperature_threshold:
+            # play_game drops to temperature 0 once len(action_history) reaches the threshold (self_play.py:163-170):
+            # a per-env, per-move switch the batch's single temperature row cannot express
+            raise NotImplementedError("play_moves does not apply config.temperature_threshold; use step()")
         if not getattr(envs, "constant_legal_actions", False):
             raise NotImplementedError("play_moves needs a game whose legal action set never changes")
         if cfg.max_moves < envs.max_episode_steps:
@@ -780,6 +904,7 @@ class DeviceSelfPlay:
         cur = self._cur
         params = (int(n_moves), float(temperature))
         if getattr(self, "_batch_ready", None) != params:
+            self.flush(on_game, on_games)                    # (the unfiled batch holds views of the download ring)
             self._drop_batch()
             eng.moves_prepare(n_moves, cur["legal"], cur["to_play"], temperature, True, num_legal=cur["num_legal"])
         ring = self._move_ring(n_moves)
@@ -806,6 +931,20 @@ class DeviceSelfPlay:
         self._cur = dict(cur, obs_dev=obs_in, obs=host["obs_next"][n_moves - 1])
         self.moves_played += int(out["moves_done"].sum())
         return out["moves_done"].copy()
+
+    def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
+        """ManyEnvLoop's pass: whole move batches on the device when the game, the network and the temperature allow
+        it (play_moves), else one move at a time (step)."""
+        batchable = (moves_per_pass is not None and not temperature_threshold and not self.config.temperature_threshold
+                     and getattr(self.envs, "constant_legal_actions", False) and self.engine._fc_model is not None
+                     and self.config.max_moves >= self.envs.max_episode_steps
+                     and (temperature == 0 or _native.exact_inverse_temperature(temperature)))
+        if not batchable:
+            return ManyEnvLoop._play_pass(self, temperature, temperature_threshold, moves_per_pass)
+        finished = []
+        self.play_moves(moves_per_pass, temperature, on_game=lambda e, gh: finished.append((e, gh)))
+        self.flush(on_game=lambda e, gh: finished.append((e, gh)))
+        return finished
 
     def flush(self, on_game=None, on_games=None):
         """File the moves of the last play_moves batch into the histories (play_moves does this for the

@@ -807,6 +807,94 @@ def g14_trainer(ctx):
     save("g14_trainer_cartpole", **out)
 
 
+class _LoopStorage:
+    """Fake shared_storage / replay_buffer for the continuous_self_play fixture: every call is logged; the
+    training step advances by `step_per_game` whenever a game is saved or a test result is stored, so the loop ends."""
+
+    def __init__(self, log, training_steps_per_event, played_steps_per_game):
+        self.log = log
+        self.info = {"training_step": 0, "terminate": False, "weights": None, "num_played_steps": 0,
+                     "num_played_games": 0}
+        self.per_event = training_steps_per_event
+        self.played = played_steps_per_game
+        outer = self
+
+        class _Remote:
+            def __init__(self, fn):
+                self.remote = fn
+        self.get_info = _Remote(self._get)
+        self.set_info = _Remote(self._set)
+        self.save_game = _Remote(self._save)
+
+    def _get(self, key):
+        self.log.append(["get_info", key])
+        return self.info[key]
+
+    def _set(self, keys, values=None):
+        self.log.append(["set_info", {k: (float(v) if v is not None else None) for k, v in keys.items()}])
+        self.info["training_step"] += self.per_event
+        return None
+
+    def _save(self, game_history, shared_storage=None):
+        self.log.append(["save_game", len(game_history.action_history) - 1])
+        self.info["training_step"] += self.per_event
+        self.info["num_played_steps"] += self.played
+        return None
+
+
+def g15_self_play_loop(ctx):
+    """SelfPlay.continuous_self_play (self_play.py:31-108) with play_game replaced by canned games: the exact
+    sequence of shared-storage / replay-buffer calls, temperatures, test-mode metric dicts and ratio sleeps."""
+    import json
+    import time as _time
+    import games.tictactoe as ttt
+    self_play, cfgs = ctx["self_play"], ctx["configs"]
+    import copy
+    out = {}
+    for name, test_mode, ratio, delay, players in (("train", False, None, 0, 2), ("train_ratio", False, 0.6, 0.25, 2),
+                                                   ("test_two_player", True, None, 0, 2), ("test_one_player", True, None, 0, 1)):
+        config = copy.deepcopy(cfgs["tictactoe"])
+        config.training_steps = 7
+        config.ratio = ratio
+        config.self_play_delay = delay
+        config.temperature_threshold = 4
+        if players == 1:
+            config.players = [0]
+        config.visit_softmax_temperature_fn = lambda trained_steps: 1.0 if trained_steps < 3 else 0.25
+        weights = {k: torch.from_numpy(v) for k, v in
+                   synthetic_state_dict(ctx["models"].MuZeroNetwork(config).state_dict(), 0).items()}
+        log = []
+        sp = self_play.SelfPlay({"weights": weights}, ttt.Game, config, 0)
+        storage = _LoopStorage(log, 2, 5)
+        storage.info["weights"] = weights
+        rs = numpy.random.RandomState(3)
+
+        def canned_play_game(temperature, temperature_threshold, render, opponent, muzero_player, rs=rs, log=log):
+            log.append(["play_game", float(temperature), temperature_threshold, bool(render), opponent, int(muzero_player)])
+            gh = self_play.GameHistory()
+            n = int(rs.randint(3, 8))
+            gh.action_history = [0] + [int(a) for a in rs.randint(0, 9, n)]
+            gh.reward_history = [0] + [float(r) for r in rs.randint(-1, 2, n)]
+            gh.to_play_history = [int(i % 2) for i in range(n + 1)]
+            gh.root_values = [float(v) for v in rs.standard_normal(n)]
+            gh.root_values[1] = 0.0                      # (mean_value skips falsy values, self_play.py:69-71)
+            gh.child_visits = [[1.0 / 9] * 9 for _ in range(n)]
+            gh.observation_history = [numpy.zeros((3, 3, 3), "float32")] * (n + 1)
+            return gh
+        sp.play_game = canned_play_game
+        sp.close_game = lambda log=log: log.append(["close_game"])
+        orig_sleep = _time.sleep
+        self_play.time.sleep = lambda t, log=log, storage=storage: (log.append(["sleep", float(t)]),
+                                                                      storage.info.__setitem__("training_step", storage.info["training_step"] + 1))
+        try:
+            sp.continuous_self_play(storage, storage, test_mode)
+        finally:
+            self_play.time.sleep = orig_sleep
+        out[name] = numpy.array(json.dumps(log))
+        print(f"   {name}: {len(log)} calls, {sum(1 for c in log if c[0] == 'play_game')} games")
+    save("g15_self_play_loop", **out)
+
+
 def g12_reference_speed(ctx):
     """How fast the reference builds training batches here (context for tools/replay_rate.py)."""
     import copy
@@ -853,7 +941,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_atari84, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer, g15_self_play_loop]
 
 
 def main():

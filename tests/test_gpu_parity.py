@@ -308,12 +308,14 @@ def native_vs_fixture(eng, model, config, fx, idx, expected_divergent=(), value_
 # reference searches.  CartPole (north-star config) keeps 1e-5 on logits and 3e-5 relative on decoded values
 # (the inverse value transform amplifies one fp32 ulp of the categorical mean ~100x).  The
 # residual networks sum their fp32 convolutions in another order than the reference's oneDNN CPU kernels; the
-# bars below are 2x the worst deviation measured on MI355X (profiles/r02_parity_report.json).
-RESNET_TOL = dict(value_tol=3e-4, logit_tol=5e-5)
+# logits still meet the north star's 1e-5 (worst measured 1.5e-6), the decoded values amplify that ~100x: the value bar
+# is 2x the worst deviation measured on MI355X (7.6e-5, profiles/r02_parity_report.json).
+RESNET_TOL = dict(value_tol=1.5e-4, logit_tol=1e-5)
 # traces whose search leaves the reference's path on MI355X because an fp32-rounding-sized difference of the
 # network outputs flips a UCB near-tie (trace index: see the report); everything else must match move for move
-# connect4: traces 21 and 23 leave the reference's path at simulation 146 / 167 of 200 (28/30 identical)
-EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (21, 23), "atari84": ()}
+# connect4: traces 9, 21 and 23 leave the reference's path at simulation 138 / 146 / 167 of 200 (27/30 identical; 21 and
+# 23 flip with MIOpen's convolution as well as with the HIP one, 9 with the HIP one only)
+EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (9, 21, 23), "atari84": ()}
 
 
 def test_native_cartpole_vs_reference(eng, models_mod):
@@ -373,7 +375,7 @@ def test_gpu_network_outputs_vs_reference_fixtures(models_mod):
                                                        torch.from_numpy(fx["actions"]).cuda())
         for got, key in ((v0, "init_value"), (p0, "init_policy"), (h0, "init_hidden"), (v1, "rec_value"),
                          (r1, "rec_reward"), (p1, "rec_policy"), (h1, "rec_hidden")):
-            tol = 1e-5 if loader == "fc" else 5e-5
+            tol = 1e-5 if loader == "fc" else 2e-5       # (hidden states are min-max rescaled: small spans amplify)
             np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=tol, atol=tol, err_msg=f"{name}:{key}")
 
 
