@@ -1,382 +1,10 @@
-// mzmcts_capi.hip -- host side of libmzmcts.so: the C ABI declared in include/mzmcts.h.
+// mzmcts_capi.hip -- host side of libmzmcts.so: the engine part of the C ABI declared in include/mzmcts.h.
 //
 // Owns the device pools, the per-tree RNG mirrors and the staging buffers; launches the kernels of
 // mcts_kernels.hip.  Launch functions do no allocation and no synchronisation (hipGraph-capturable);
-// everything blocking says so in the header.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <functional>
-#include <initializer_list>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/mzhist.h"
-#include "../../include/mzmcts.h"
-#include "fc_net_device.h"
-#include "kernel_common.h"
-#include "narrow_device.h"
-#include "np_legacy_rng.h"
-#include "tree_layout.h"
-
-namespace mz {
-int default_group_width(int A);
-hipError_t launch_fc_inference(const TreeParams& p, const FcNet& net, const float* weights, bool initial, const float* in,
-                               const int64_t* action, float* value_logits, float* reward_logits, float* policy_logits,
-                               float* hidden_out, hipStream_t stream);
-bool plan_fused_layout(const TreeParams& p, const FcNet& net, bool want_hidden_in_lds, size_t lds_limit,
-                       FusedLayout* out);
-bool narrow_supported(const TreeParams& p, const FcNet& net);
-bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit, NarrowLayout* out);
-hipError_t launch_search_fused_narrow(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
-                                      const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
-                                      hipStream_t stream, const LaunchTiming* timing);
-hipError_t launch_fc_inference_narrow(const TreeParams& p, const FcNet& net, const float* weights, bool initial,
-                                      const float* in, const int64_t* action, float* value_logits, float* reward_logits,
-                                      float* policy_logits, float* hidden_out, hipStream_t stream);
-hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
-                                  const float* observations, const MoveCtl& ctl, int n_sims, hipStream_t stream,
-                                  const LaunchTiming* timing);
-hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
-                         const LaunchTiming* timing);
-hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
-                                        hipStream_t stream);
-hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
-                               const float* policy_logits, const float* root_hidden, const double* inj_reward,
-                               const double* inj_priors, const double* noise, const uint32_t* rng_skip,
-                               bool injected, hipStream_t stream, const LaunchTiming* timing);
-hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
-                                const float* policy_logits, const double* inj_value, const double* inj_reward,
-                                const double* inj_priors, bool injected, hipStream_t stream,
-                                const LaunchTiming* timing);
-hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t stream);
-hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
-}  // namespace mz
-
-#ifdef MZ_STAMPS
-namespace mz {
-hipError_t read_stamp_sums(unsigned long long* out, bool reset);
-hipError_t read_stamp_sums_narrow(unsigned long long* out, bool reset);
-}
-#endif
-
-namespace {
-thread_local std::string g_create_error;
-
-enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfFused = 3 };
-constexpr size_t kLdsPerWorkgroup = 160 * 1024;  // gfx950
-struct EventPair {
-    hipEvent_t begin, end;
-    int kind;
-};
-
-// Persistent, process-wide worker pool for the per-env host work of a move (Dirichlet draws, action
-// sampling, readout unpacking).  Workers spin briefly on the job generation before sleeping: in a
-// self-play loop the next job arrives within microseconds, and a condition-variable wake-up costs more
-// than the work itself at a few thousand envs.
-class WorkerPool {
-  public:
-    explicit WorkerPool(int workers) {
-        for (int i = 0; i < workers; ++i) threads_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lock(mu_);
-            stop_.store(true, std::memory_order_release);
-            generation_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    int size() const { return static_cast<int>(threads_.size()); }
-    // body(lo, hi) over [0, n) in small chunks claimed dynamically by the workers and the caller.  The job is
-    // complete when every CHUNK is done, not when every worker has reported: on a busy host a worker that is
-    // descheduled (or still asleep) delays nothing it has not claimed.
-    void run(int n, const std::function<void(int, int)>& body) {
-        std::lock_guard<std::mutex> serial(run_mu_);  // one job at a time (engines share the pool)
-        const int per_thread = 4;
-        int chunk = n / ((size() + 1) * per_thread);
-        if (chunk < 16) chunk = 16;
-        const uint64_t g = generation_.load(std::memory_order_relaxed) + 1;
-        const uint32_t total = static_cast<uint32_t>((n + chunk - 1) / chunk);
-        body_.store(&body, std::memory_order_relaxed);
-        n_.store(n, std::memory_order_relaxed);
-        chunk_.store(chunk, std::memory_order_relaxed);
-        total_.store(total, std::memory_order_relaxed);
-        done_.store(0, std::memory_order_relaxed);
-        next_.store(g << 32, std::memory_order_release);  // publishes the fields above for generation g
-        {
-            std::lock_guard<std::mutex> lock(mu_);
-            generation_.store(g, std::memory_order_release);
-        }
-        cv_.notify_all();
-        work(g);
-        while (done_.load(std::memory_order_acquire) < total) __builtin_ia32_pause();
-        // Close the job: a worker that read the claim word before this point and was descheduled must fail its
-        // compare-exchange instead of claiming a chunk of whatever job comes next.
-        next_.store((g << 32) | kClosed, std::memory_order_release);
-        body_.store(nullptr, std::memory_order_relaxed);
-    }
-
-  private:
-    static constexpr uint32_t kClosed = 0xffffffffu;
-    // claim chunks of generation g until none is left (or the job has moved on)
-    void work(uint64_t g) {
-        for (;;) {
-            uint64_t cur = next_.load(std::memory_order_acquire);
-            if ((cur >> 32) != g) return;
-            const uint32_t idx = static_cast<uint32_t>(cur & 0xffffffffu);
-            if (idx >= total_.load(std::memory_order_relaxed)) return;
-            // a successful exchange proves the claim word still belongs to generation g, hence so do the fields
-            if (!next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
-            const int chunk = chunk_.load(std::memory_order_relaxed);
-            const int lo = static_cast<int>(idx) * chunk, hi = std::min(n_.load(std::memory_order_relaxed), lo + chunk);
-            (*body_.load(std::memory_order_relaxed))(lo, hi);  // the job cannot complete before this chunk is counted
-            done_.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            // spin for the next job, then fall back to sleeping
-            bool have = false;
-            for (int spin = 0; spin < 20000; ++spin) {
-                if (generation_.load(std::memory_order_acquire) != seen) {
-                    have = true;
-                    break;
-                }
-                __builtin_ia32_pause();
-            }
-            if (!have) {
-                std::unique_lock<std::mutex> lock(mu_);
-                cv_.wait(lock, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-            }
-            seen = generation_.load(std::memory_order_acquire);
-            if (stop_.load(std::memory_order_acquire)) return;
-            work(seen);
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex mu_, run_mu_;
-    std::condition_variable cv_;
-    std::atomic<const std::function<void(int, int)>*> body_{nullptr};
-    std::atomic<int> n_{0}, chunk_{0};
-    std::atomic<uint32_t> total_{0}, done_{0};
-    std::atomic<uint64_t> next_{0};
-    std::atomic<uint64_t> generation_{0};
-    std::atomic<bool> stop_{false};
-};
-
-int host_worker_count(int n_items) {
-    int hw = static_cast<int>(std::thread::hardware_concurrency());
-    if (hw <= 0) hw = 1;
-    if (const char* env = std::getenv("MZMCTS_HOST_THREADS")) hw = std::max(1, std::atoi(env));
-    (void)n_items;
-    return std::max(0, std::min(hw, 16) - 1);
-}
-
-WorkerPool& shared_pool() {
-    static WorkerPool pool(host_worker_count(0));
-    return pool;
-}
-
-}  // namespace
-
-struct mzmcts_engine {
-    mzmcts_config cfg{};
-    mz::TreeParams p{};
-    std::string error;
-    int sim = 0;            // simulations launched since expand_roots
-    bool roots_ready = false;
-    bool search_begun = false;
-    bool have_readout = false;
-    bool owns_hidden = false;
-    int64_t device_bytes = 0;
-
-    // device staging for the per-move host inputs
-    double* d_noise = nullptr;
-    uint32_t* d_skip = nullptr;
-    uint32_t* d_seeds = nullptr;
-    bool noise_this_search = false;
-
-    // pinned host staging
-    int32_t* h_legal = nullptr;      // [E][A]
-    int32_t* h_nlegal = nullptr;     // [E]
-    int32_t* h_to_play = nullptr;    // [E]
-    double* h_noise = nullptr;       // [E][A]
-    uint32_t* h_skip = nullptr;      // [E]
-    uint8_t* h_slab0 = nullptr;      // [E][block_stride]
-    double* h_root_value_sum = nullptr;
-    float* h_root_predicted = nullptr;
-    int32_t* h_max_depth = nullptr;
-    int64_t* h_depth_sum = nullptr;
-    uint32_t* h_tie_words = nullptr;
-    mz::MinMax* h_min_max = nullptr;
-    int32_t* h_error_flag = nullptr;
-
-    // host RNG mirrors; lag[e] = words the host stream is ahead of the device copy
-    std::vector<mz::HostStream> streams;
-    std::vector<uint32_t> lag;
-
-    // cache of the last readout (sample_actions / search_statistics)
-    std::vector<int32_t> last_visits;       // [E][A] per slot
-    std::vector<double> last_root_value_sum;
-    std::vector<int32_t> last_root_visits;
-
-    // fully-connected network for the in-kernel inference paths
-    bool fc_ready = false;
-    int fused_variant = MZMCTS_FUSED_AUTO;  // which whole-move kernel mzmcts_search_fused_fc launches
-    bool publish_tree = true;               // fused kernels copy the whole tree out (export_tree) or the root only
-    bool tree_published = true;             // false after a root-only fused search
-    mz::FcNet fc{};
-    const float* fc_weights = nullptr;
-
-    // profiling
-    bool profiling = false;
-    std::vector<EventPair> events;
-    size_t events_used = 0;
-    mzmcts_profile prof{};
-
-    std::vector<void*> device_allocs;
-    std::vector<void*> pinned_allocs;
-
-    // packed per-move upload ([legal | num_legal | to_play | rng_skip | noise]) and per-tree download
-    uint8_t* h_upload = nullptr;
-    uint8_t* d_upload = nullptr;
-    size_t upload_bytes = 0, upload_bytes_no_noise = 0;
-    uint8_t* h_download = nullptr;
-    uint8_t* d_download = nullptr;
-    size_t download_bytes = 0;
-    bool tie_words_applied = false;
-
-    // batches of moves queued back to back (mzmcts_moves_*)
-    struct MoveRecord {
-        int32_t pos, has_gauss;
-        double gauss;
-        uint64_t words;
-    };
-    // One batch's host side: the noise rows, and what is needed to take the RNG mirror back to any point of it.
-    struct ChainSet {
-        int n_moves = 0;
-        bool add_noise = false;
-        bool drawn = false;
-        bool speculative = false;                    // drawn on top of a batch that was still in flight
-        uint8_t* h_in = nullptr;                     // pinned [noise M*E*A f64 | skip M*E u32 | temperature E f64 |
-                                                     //         limit E i32 | expected ties E u32]
-        std::vector<int32_t> legal, nlegal, to_play; // [E][A], [E], [E]
-        std::vector<MoveRecord> start;               // [E] mirror state before this batch's first draw
-        std::vector<uint32_t> start_lag;             // [E]
-        std::vector<MoveRecord> rec;                 // [M][E] mirror state right after move m's noise was drawn
-        std::vector<uint8_t> env_twisted;            // [E] the 624-word block was regenerated during the draws
-        std::vector<uint64_t> twist_words;           // [E] word count at the first such regeneration
-        std::vector<uint32_t> twist_keys;            // [E][624] the block just before it
-        std::vector<double> temperature;             // [E]
-        std::vector<uint32_t> tail_ties, tail_sample;  // [E] words assumed for the last move of the batch underneath
-        std::vector<uint8_t> deferred;               // [E] speculative set: rows not drawn yet (unknown word counts)
-    };
-    struct MoveBatch {
-        int capacity = 0, enqueued = 0;
-        bool in_flight = false;                      // set[cur] is uploaded (prepare / submit_next) and not collected
-        int cur = 0;
-        ChainSet set[2];
-        size_t out_stride = 0;                       // bytes of one move's output block
-        size_t o_actions = 0, o_visits = 0, o_rvs = 0, o_pred = 0, o_depth = 0, o_ties = 0, o_sample = 0, o_dsum = 0;
-        size_t in_bytes = 0, o_skip = 0, o_temp = 0, o_limit = 0, o_expect = 0;
-        uint8_t* d_in = nullptr;
-        uint8_t *h_out = nullptr, *d_out = nullptr;  // [M] output blocks
-        uint8_t* d_stall = nullptr;
-        hipEvent_t done = nullptr;
-    } batch;
-
-    // pending asynchronous readout (mzmcts_readout_begin)
-    hipEvent_t readout_event = nullptr;
-    bool readout_pending = false;
-
-    void for_each_env(const std::function<void(int, int)>& body) {
-        WorkerPool& pool = shared_pool();
-        if (pool.size() > 0 && p.E >= 512)
-            pool.run(p.E, body);
-        else
-            body(0, p.E);
-    }
-};
-
-namespace {
-
-int fail(mzmcts_engine* eng, int code, const std::string& msg) {
-    if (eng) eng->error = msg;
-    g_create_error = msg;
-    return code;
-}
-
-int hip_fail(mzmcts_engine* eng, hipError_t err, const char* what) {
-    return fail(eng, MZMCTS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
-}
-
-#define MZ_HIP(eng, call)                                         \
-    do {                                                          \
-        hipError_t err__ = (call);                                \
-        if (err__ != hipSuccess) return hip_fail(eng, err__, #call); \
-    } while (0)
-
-template <typename T>
-int dev_alloc(mzmcts_engine* eng, T** out, size_t count, bool zero = true) {
-    void* ptr = nullptr;
-    const size_t bytes = count * sizeof(T);
-    MZ_HIP(eng, hipMalloc(&ptr, bytes ? bytes : 16));
-    if (zero) MZ_HIP(eng, hipMemset(ptr, 0, bytes ? bytes : 16));
-    eng->device_allocs.push_back(ptr);
-    eng->device_bytes += static_cast<int64_t>(bytes);
-    *out = static_cast<T*>(ptr);
-    return 0;
-}
-
-template <typename T>
-int pinned_alloc(mzmcts_engine* eng, T** out, size_t count) {
-    void* ptr = nullptr;
-    const size_t bytes = count * sizeof(T);
-    MZ_HIP(eng, hipHostMalloc(&ptr, bytes ? bytes : 16, hipHostMallocDefault));
-    std::memset(ptr, 0, bytes ? bytes : 16);
-    eng->pinned_allocs.push_back(ptr);
-    *out = static_cast<T*>(ptr);
-    return 0;
-}
-
-bool stream_is_capturing(hipStream_t s) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
-    return st != hipStreamCaptureStatusNone;
-}
-
-// In profiling mode (never while capturing) hand the launcher an event pair that HIP binds to the
-// kernel dispatch itself, so the elapsed time is the kernel's own duration.
-struct ProfScope {
-    mz::LaunchTiming timing;
-    ProfScope(mzmcts_engine* eng, hipStream_t s, int kind) {
-        if (!eng->profiling || stream_is_capturing(s)) return;
-        if (eng->events_used == eng->events.size()) {
-            EventPair np{};
-            if (hipEventCreate(&np.begin) != hipSuccess || hipEventCreate(&np.end) != hipSuccess) return;
-            eng->events.push_back(np);
-        }
-        EventPair& pair = eng->events[eng->events_used++];
-        pair.kind = kind;
-        timing.start = pair.begin;
-        timing.stop = pair.end;
-    }
-    const mz::LaunchTiming* get() const { return timing.start ? &timing : nullptr; }
-};
-
-}  // namespace
+// everything blocking says so in the header.  Move batches live in mzmcts_moves.hip, the stand-alone RNG ABI in
+// mzmcts_rng.hip, the history filer in mzhist.hip; the shared engine state in engine_host.h.
+#include "engine_host.h"
 
 extern "C" {
 
@@ -1106,11 +734,15 @@ int mzmcts_fc_configure(mzmcts_engine* eng, const mzmcts_fc_desc* d, const float
 
 // The narrow kernels (fused_narrow.hip) run when the network qualifies and the caller did not ask for the
 // generic ones; asking for them on a network that does not qualify is reported by mzmcts_set_fused_options.
-static bool use_narrow(const mzmcts_engine* eng) {
+}  // extern "C"
+
+bool mzhost_use_narrow(const mzmcts_engine* eng) {
     if (!eng->fc_ready || eng->fused_variant == MZMCTS_FUSED_GENERIC) return false;
     mz::NarrowLayout lay{};
     return mz::narrow_supported(eng->p, eng->fc) && mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &lay);
 }
+
+extern "C" {
 
 int mzmcts_set_fused_options(mzmcts_engine* eng, int32_t variant, int32_t publish_tree) {
     if (!eng) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_fused_options: null engine");
@@ -1130,7 +762,7 @@ int mzmcts_set_fused_options(mzmcts_engine* eng, int32_t variant, int32_t publis
 
 int32_t mzmcts_fused_variant(mzmcts_engine* eng) {
     if (!eng || !eng->fc_ready) return 0;
-    if (use_narrow(eng)) return MZMCTS_FUSED_NARROW;
+    if (mzhost_use_narrow(eng)) return MZMCTS_FUSED_NARROW;
     mz::FusedLayout lay{};
     return mz::plan_fused_layout(eng->p, eng->fc, true, kLdsPerWorkgroup, &lay) ? MZMCTS_FUSED_GENERIC : 0;
 }
@@ -1140,7 +772,7 @@ int mzmcts_fc_initial_inference(mzmcts_engine* eng, const float* observations, f
     if (!eng || !observations || !value_logits || !reward_logits || !policy_logits || !hidden_out)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_initial_inference: call mzmcts_fc_configure first");
-    if (use_narrow(eng))
+    if (mzhost_use_narrow(eng))
         MZ_HIP(eng, mz::launch_fc_inference_narrow(eng->p, eng->fc, eng->fc_weights, true, observations, nullptr,
                                                    value_logits, reward_logits, policy_logits, hidden_out,
                                                    static_cast<hipStream_t>(stream)));
@@ -1155,7 +787,7 @@ int mzmcts_fc_recurrent_inference(mzmcts_engine* eng, const float* hidden, const
     if (!eng || !hidden || !action || !value_logits || !reward_logits || !policy_logits || !hidden_out)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_fc_recurrent_inference: call mzmcts_fc_configure first");
-    if (use_narrow(eng))
+    if (mzhost_use_narrow(eng))
         MZ_HIP(eng, mz::launch_fc_inference_narrow(eng->p, eng->fc, eng->fc_weights, false, hidden, action, value_logits,
                                                    reward_logits, policy_logits, hidden_out,
                                                    static_cast<hipStream_t>(stream)));
@@ -1167,7 +799,7 @@ int mzmcts_fc_recurrent_inference(mzmcts_engine* eng, const float* hidden, const
 
 int64_t mzmcts_fused_lds_bytes(mzmcts_engine* eng, int32_t hidden_in_lds) {
     if (!eng || !eng->fc_ready) return 0;
-    if (use_narrow(eng)) {
+    if (mzhost_use_narrow(eng)) {
         mz::NarrowLayout nl{};
         mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
         return nl.total_bytes;
@@ -1177,10 +809,12 @@ int64_t mzmcts_fused_lds_bytes(mzmcts_engine* eng, int32_t hidden_in_lds) {
     return lay.total_bytes;
 }
 
-// One whole-move kernel (narrow or generic, see use_narrow) with the given per-move control block.
-static int launch_fused_move(mzmcts_engine* eng, const float* observations, const mz::MoveCtl& ctl, bool hidden_in_lds,
+}  // extern "C"
+
+// One whole-move kernel (narrow or generic, see mzhost_use_narrow) with the given per-move control block.
+int mzhost_launch_fused_move(mzmcts_engine* eng, const float* observations, const mz::MoveCtl& ctl, bool hidden_in_lds,
                              hipStream_t stream) {
-    if (use_narrow(eng)) {
+    if (mzhost_use_narrow(eng)) {
         mz::NarrowLayout nl{};
         mz::plan_narrow_layout(eng->p, eng->fc, kLdsPerWorkgroup, &nl);
         ProfScope scope(eng, stream, kProfFused);
@@ -1200,6 +834,8 @@ static int launch_fused_move(mzmcts_engine* eng, const float* observations, cons
     return MZMCTS_OK;
 }
 
+extern "C" {
+
 int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_t hidden_in_lds, void* stream_) {
     if (!eng || !observations) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: null argument");
     if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_search_fused_fc: call mzmcts_fc_configure first");
@@ -1208,7 +844,7 @@ int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_
     mz::MoveCtl ctl{};
     ctl.noise = eng->noise_this_search ? eng->d_noise : nullptr;
     ctl.rng_skip = eng->d_skip;
-    int rc = launch_fused_move(eng, observations, ctl, hidden_in_lds != 0, stream);
+    int rc = mzhost_launch_fused_move(eng, observations, ctl, hidden_in_lds != 0, stream);
     if (rc) return rc;
     eng->roots_ready = true;
     eng->sim = eng->p.S;
@@ -1216,451 +852,6 @@ int mzmcts_search_fused_fc(mzmcts_engine* eng, const float* observations, int32_
 }
 
 
-// ---- batches of moves without host round trips ---------------------------------------------------------------
-// Stream bookkeeping.  Per env the numpy stream is consumed, move after move, as
-//     [Dirichlet(m)] [tie-breaks of search m] [select_action(m)]      (self_play.py:303-315, 372-378, 223-246)
-// The host draws every Dirichlet row of a batch up front on its mirror, assuming search m spends one word on
-// the unavoidable first-simulation tie (none with a single legal action) and select_action consumes what the
-// temperature implies (0 words at T = 0, 2 at T = 1); the kernels consume the tie-break and sampling words on
-// the device copy and skip the Dirichlet words (rng_skip ring).  An env whose search spent a different number
-// of tie-break words stalls from the next move on (kernel_common.h); collect() puts the mirror back to the
-// state recorded after the last noise row that was really used and replays what the device consumed.
-// The NEXT batch may be drawn the same way while the current one is still running (predraw_next): collect()
-// then also redraws, from the true stream position, the rows of every env whose current batch did not end as
-// assumed, before submit_next() uploads them.
-using ChainSet = mzmcts_engine::ChainSet;
-using MoveRecord = mzmcts_engine::MoveRecord;
-
-// Take env e's mirror back (or forward) to `target`, a state recorded while drawing sets[0..n_sets) (oldest
-// first).  Only the first regeneration of a set is backed up, so: if a backed-up block covers the target, use
-// it directly; otherwise start from the latest backup before the target and walk forward.
-static void restore_stream(mzmcts_engine* eng, int e, const MoveRecord& target, ChainSet* const* sets, int n_sets) {
-    mz::HostStream& s = eng->streams[e];
-    const ChainSet* before = nullptr;
-    const ChainSet* covering = nullptr;
-    for (int i = 0; i < n_sets; ++i) {
-        const ChainSet* c = sets[i];
-        if (!c || !c->drawn || !c->env_twisted[e]) continue;
-        if (c->twist_words[e] < target.words)
-            before = c;
-        else if (!covering)
-            covering = c;
-    }
-    if (before) {
-        std::memcpy(s.key, before->twist_keys.data() + static_cast<size_t>(e) * mz::kMtN, sizeof(s.key));
-        s.pos = mz::kMtN;
-        s.words = before->twist_words[e];
-        s.skip(target.words - s.words);
-    } else {
-        if (covering) std::memcpy(s.key, covering->twist_keys.data() + static_cast<size_t>(e) * mz::kMtN, sizeof(s.key));
-        s.pos = target.pos;
-        s.words = target.words;
-    }
-    s.has_gauss = target.has_gauss;
-    s.gauss = target.gauss;
-}
-
-static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (n_moves <= b.capacity) return 0;
-    if (b.in_flight || b.set[0].drawn || b.set[1].drawn)
-        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves: a larger batch needs new buffers; collect the batches in flight first");
-    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A), M = static_cast<size_t>(n_moves);
-    auto align = [](size_t v) { return (v + 255) / 256 * 256; };
-    b.o_skip = align(sizeof(double) * M * E * A);
-    b.o_temp = align(b.o_skip + sizeof(uint32_t) * M * E);
-    b.o_limit = align(b.o_temp + sizeof(double) * E);
-    b.o_expect = align(b.o_limit + sizeof(int32_t) * E);
-    b.in_bytes = align(b.o_expect + sizeof(uint32_t) * E);
-    b.o_actions = 0;
-    b.o_visits = align(sizeof(int32_t) * E);
-    b.o_rvs = align(b.o_visits + sizeof(int32_t) * E * A);
-    b.o_pred = align(b.o_rvs + sizeof(double) * E);
-    b.o_depth = align(b.o_pred + sizeof(float) * E);
-    b.o_ties = align(b.o_depth + sizeof(int32_t) * E);
-    b.o_sample = align(b.o_ties + sizeof(uint32_t) * E);
-    b.o_dsum = align(b.o_sample + sizeof(uint32_t) * E);
-    b.out_stride = align(b.o_dsum + sizeof(int32_t) * E);
-    int rc;  // (earlier, smaller buffers stay registered with the engine and are freed with it)
-    if ((rc = dev_alloc(eng, &b.d_in, b.in_bytes))) return rc;
-    if ((rc = dev_alloc(eng, &b.d_out, b.out_stride * M))) return rc;
-    if ((rc = pinned_alloc(eng, &b.h_out, b.out_stride * M))) return rc;
-    if (!b.d_stall && (rc = dev_alloc(eng, &b.d_stall, E))) return rc;
-    if (!b.done) MZ_HIP(eng, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-    for (ChainSet& c : b.set) {
-        if ((rc = pinned_alloc(eng, &c.h_in, b.in_bytes))) return rc;
-        c.legal.assign(E * A, 0);
-        c.nlegal.assign(E, 0);
-        c.to_play.assign(E, 0);
-        c.start.resize(E);
-        c.start_lag.assign(E, 0);
-        c.rec.resize(M * E);
-        c.env_twisted.assign(E, 0);
-        c.twist_words.assign(E, 0);
-        c.twist_keys.resize(E * mz::kMtN);
-        c.temperature.assign(E, 0.0);
-        c.tail_ties.assign(E, 0);
-        c.tail_sample.assign(E, 0);
-        c.deferred.assign(E, 0);
-    }
-    b.capacity = n_moves;
-    // Run both transfers once at full size: the runtime sets up its large-copy path on first use (tens of
-    // milliseconds), which would otherwise land in the first full-size batch.
-    MZ_HIP(eng, hipMemcpy(b.d_in, b.set[0].h_in, b.in_bytes, hipMemcpyHostToDevice));
-    MZ_HIP(eng, hipMemcpy(b.h_out, b.d_out, b.out_stride * M, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-static int check_move_inputs(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
-                             const int32_t* to_play, const double* temperature, const char* who) {
-    if (!eng || !legal || !num_legal || !to_play || !temperature) return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": null argument");
-    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": call mzmcts_fc_configure first");
-    if (n_moves < 1 || n_moves > 4096) return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": n_moves out of range");
-    const int E = eng->p.E, A = eng->p.A;
-    for (int e = 0; e < E; ++e) {
-        const int n = num_legal[e];
-        if (n < 0 || n > A)
-            return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
-        for (int i = 0; i < n; ++i) {
-            const int a = legal[static_cast<size_t>(e) * A + i];
-            if (a < 0 || a >= A)
-                return fail(eng, MZMCTS_ERR_LEGAL_RANGE, "Legal actions should be a subset of the action space.");
-        }
-        const double t = temperature[e];
-        if (!(t == 0.0 || std::isinf(t) || (mz::exact_inverse_temperature(t) && std::pow(eng->p.S, 1.0 / t) < 9.0e15)))
-            return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": the device samples actions at temperature 0, inf or 1/k, "
-                                                                    "k = 1..4, only (visit_count ** (1 / T) needs the host's pow)");
-    }
-    return 0;
-}
-
-// words select_action consumes on the device; +inf draws a bounded integer by rejection: unknown in advance
-static int assumed_sample_words(double t) { return (t == 0.0) ? 0 : (std::isinf(t) ? -1 : 2); }
-// The first simulation always ties: the root has no visits yet, so every child scores 0 (sqrt(0) in ucb_score,
-// self_play.py:385-390) and select_child draws numpy.random.choice over all n of them -- one masked 32-bit word
-// when n is a power of two, a rejection loop otherwise (one word is the likeliest outcome and the one assumed).
-// Later ties need exactly equal fp64 scores.
-static uint32_t assumed_tie_words(int n) { return n > 1 ? 1u : 0u; }
-
-// Draw env e's rows of set c from the mirror's current state.  `tail`: the mirror stands right after the
-// previous batch's last noise row and that batch has not finished -- first step over what its last move is
-// assumed to consume.  Returns false (nothing drawn) when that cannot be known in advance.
-static bool draw_env_rows(mzmcts_engine* eng, ChainSet& c, int e, bool tail, const ChainSet* under) {
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    const int E = eng->p.E, A = eng->p.A, n_moves = c.n_moves;
-    const size_t EA = static_cast<size_t>(E) * A;
-    double* h_noise = reinterpret_cast<double*>(c.h_in);
-    uint32_t* h_skip = reinterpret_cast<uint32_t*>(c.h_in + b.o_skip);
-    double* h_temp = reinterpret_cast<double*>(c.h_in + b.o_temp);
-    int32_t* h_limit = reinterpret_cast<int32_t*>(c.h_in + b.o_limit);
-    uint32_t* h_expect = reinterpret_cast<uint32_t*>(c.h_in + b.o_expect);
-    const int n = c.nlegal[e];
-    const double t = c.temperature[e];
-    const int assumed = assumed_sample_words(t);
-    const uint32_t tie_words = assumed_tie_words(n);
-    h_temp[e] = t;
-    h_limit[e] = (n == 0) ? 0 : (assumed < 0 ? 1 : n_moves);
-    h_expect[e] = tie_words;
-    c.env_twisted[e] = 0;
-    c.deferred[e] = 0;
-    mz::HostStream& s = eng->streams[e];
-    uint32_t lag0 = eng->lag[e];
-    if (tail && n > 0) {
-        const int under_n = under->nlegal[e];
-        const int under_sample = assumed_sample_words(under->temperature[e]);
-        if (under_n > 0 && under_sample < 0) {  // the batch underneath samples at T = inf: draw these rows at collect()
-            c.deferred[e] = 1;
-            h_limit[e] = 0;
-            for (int m = 0; m < n_moves; ++m) {
-                h_skip[static_cast<size_t>(m) * E + e] = 0;
-                for (int i = 0; i < A; ++i) h_noise[static_cast<size_t>(m) * EA + static_cast<size_t>(e) * A + i] = 0.0;
-            }
-            return false;
-        }
-    }
-    c.start[e] = MoveRecord{s.pos, s.has_gauss, s.gauss, s.words};
-    c.start_lag[e] = lag0;
-    s.twist_backup = c.twist_keys.data() + static_cast<size_t>(e) * mz::kMtN;
-    s.twisted = false;
-    c.tail_ties[e] = 0;
-    c.tail_sample[e] = 0;
-    if (tail && n > 0 && under->nlegal[e] > 0) {
-        c.tail_ties[e] = assumed_tie_words(under->nlegal[e]);
-        c.tail_sample[e] = static_cast<uint32_t>(assumed_sample_words(under->temperature[e]));
-        s.skip(static_cast<uint64_t>(c.tail_ties[e]) + c.tail_sample[e]);
-        lag0 = 0;  // the batch underneath hands the device copy over in step with the mirror
-    }
-    const double alpha = eng->cfg.root_dirichlet_alpha;
-    for (int m = 0; m < n_moves; ++m) {
-        double* row = h_noise + static_cast<size_t>(m) * EA + static_cast<size_t>(e) * A;
-        for (int i = 0; i < A; ++i) row[i] = 0.0;
-        uint32_t skip = 0;
-        if (n > 0 && m < h_limit[e]) {
-            if (m > 0) s.skip(static_cast<uint64_t>(tie_words) + static_cast<uint64_t>(assumed));
-            const uint64_t before = s.words;
-            if (c.add_noise) s.dirichlet(alpha, n, row);
-            skip = static_cast<uint32_t>(s.words - before) + (m == 0 ? lag0 : 0u);
-        }
-        h_skip[static_cast<size_t>(m) * E + e] = skip;
-        c.rec[static_cast<size_t>(m) * E + e] = MoveRecord{s.pos, s.has_gauss, s.gauss, s.words};
-    }
-    if (n > 0) eng->lag[e] = 0;
-    c.env_twisted[e] = s.twisted ? 1 : 0;
-    c.twist_words[e] = s.twist_words;
-    s.twist_backup = nullptr;
-    s.twisted = false;
-    return true;
-}
-
-static void fill_set(mzmcts_engine* eng, ChainSet& c, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
-                     const int32_t* to_play, int32_t add_noise, const double* temperature) {
-    const int E = eng->p.E, A = eng->p.A;
-    std::memcpy(c.legal.data(), legal, sizeof(int32_t) * static_cast<size_t>(E) * A);
-    std::memcpy(c.nlegal.data(), num_legal, sizeof(int32_t) * E);
-    std::memcpy(c.to_play.data(), to_play, sizeof(int32_t) * E);
-    std::memcpy(c.temperature.data(), temperature, sizeof(double) * E);
-    c.n_moves = n_moves;
-    c.add_noise = add_noise != 0;
-}
-
-static int upload_set(mzmcts_engine* eng, ChainSet& c, hipStream_t stream) {
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    const int E = eng->p.E, A = eng->p.A;
-    std::memcpy(eng->h_legal, c.legal.data(), sizeof(int32_t) * static_cast<size_t>(E) * A);
-    std::memcpy(eng->h_nlegal, c.nlegal.data(), sizeof(int32_t) * E);
-    std::memcpy(eng->h_to_play, c.to_play.data(), sizeof(int32_t) * E);
-    MZ_HIP(eng, hipMemcpyAsync(eng->d_upload, eng->h_upload, eng->upload_bytes_no_noise, hipMemcpyHostToDevice, stream));
-    MZ_HIP(eng, hipMemcpyAsync(b.d_in, c.h_in, b.in_bytes, hipMemcpyHostToDevice, stream));
-    MZ_HIP(eng, hipMemsetAsync(b.d_stall, 0, static_cast<size_t>(E), stream));
-    b.enqueued = 0;
-    b.in_flight = true;
-    eng->search_begun = false;
-    eng->roots_ready = false;
-    eng->have_readout = false;
-    return MZMCTS_OK;
-}
-
-int mzmcts_moves_prepare(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
-                         const int32_t* to_play, int32_t add_noise, const double* temperature, void* stream_) {
-    int rc = check_move_inputs(eng, n_moves, legal, num_legal, to_play, temperature, "mzmcts_moves_prepare");
-    if (rc) return rc;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (b.in_flight || b.set[b.cur ^ 1].drawn)
-        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: collect the previous batch first");
-    if ((rc = ensure_batch_capacity(eng, n_moves))) return rc;
-    ChainSet& c = b.set[b.cur];
-    fill_set(eng, c, n_moves, legal, num_legal, to_play, add_noise, temperature);
-    eng->for_each_env([&](int lo, int hi) {
-        for (int e = lo; e < hi; ++e) draw_env_rows(eng, c, e, false, nullptr);
-    });
-    c.drawn = true;
-    c.speculative = false;
-    return upload_set(eng, c, static_cast<hipStream_t>(stream_));
-}
-
-int mzmcts_moves_predraw_next(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
-                              const int32_t* to_play, int32_t add_noise, const double* temperature) {
-    int rc = check_move_inputs(eng, n_moves, legal, num_legal, to_play, temperature, "mzmcts_moves_predraw_next");
-    if (rc) return rc;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (!b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: no batch in flight (use mzmcts_moves_prepare)");
-    if (b.set[b.cur ^ 1].drawn) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: the next batch is already drawn");
-    if (n_moves > b.capacity)
-        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: larger than the batch in flight (its buffers are in use)");
-    ChainSet& under = b.set[b.cur];
-    ChainSet& c = b.set[b.cur ^ 1];
-    fill_set(eng, c, n_moves, legal, num_legal, to_play, add_noise, temperature);
-    eng->for_each_env([&](int lo, int hi) {
-        for (int e = lo; e < hi; ++e) draw_env_rows(eng, c, e, true, &under);
-    });
-    c.drawn = true;
-    c.speculative = true;
-    return MZMCTS_OK;
-}
-
-int mzmcts_moves_submit_next(mzmcts_engine* eng, void* stream_) {
-    if (!eng) return MZMCTS_ERR_INVALID;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_submit_next: collect the batch in flight first");
-    ChainSet& c = b.set[b.cur ^ 1];
-    if (!c.drawn) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_submit_next: no pre-drawn batch (mzmcts_moves_predraw_next)");
-    b.cur ^= 1;
-    c.speculative = false;
-    return upload_set(eng, c, static_cast<hipStream_t>(stream_));
-}
-
-int mzmcts_moves_discard_next(mzmcts_engine* eng) {
-    if (!eng) return MZMCTS_ERR_INVALID;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_discard_next: collect the batch in flight first");
-    ChainSet& c = b.set[b.cur ^ 1];
-    if (!c.drawn) return MZMCTS_OK;
-    ChainSet* sets[1] = {&c};
-    eng->for_each_env([&](int lo, int hi) {
-        for (int e = lo; e < hi; ++e) {
-            if (c.deferred[e]) continue;  // nothing was drawn for this env
-            restore_stream(eng, e, c.start[e], sets, 1);
-            // what the finished batch's last move consumed was confirmed by its collect(): step over it again
-            eng->streams[e].skip(static_cast<uint64_t>(c.tail_ties[e]) + c.tail_sample[e]);
-            eng->lag[e] = (c.tail_ties[e] | c.tail_sample[e]) ? 0u : c.start_lag[e];
-        }
-    });
-    c.drawn = false;
-    return MZMCTS_OK;
-}
-
-int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* stream_) {
-    if (!eng || !observations) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: null argument");
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    const ChainSet& c = b.set[b.cur];
-    if (!b.in_flight || b.enqueued >= c.n_moves)
-        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: no prepared move left in the batch");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A);
-    const int m = b.enqueued;
-    uint8_t* out = b.d_out + b.out_stride * static_cast<size_t>(m);
-    mz::MoveCtl ctl{};
-    ctl.noise = c.add_noise ? reinterpret_cast<const double*>(b.d_in) + static_cast<size_t>(m) * E * A : nullptr;
-    ctl.rng_skip = reinterpret_cast<const uint32_t*>(b.d_in + b.o_skip) + static_cast<size_t>(m) * E;
-    ctl.temperature = reinterpret_cast<const double*>(b.d_in + b.o_temp);
-    ctl.move_limit = reinterpret_cast<const int32_t*>(b.d_in + b.o_limit);
-    ctl.stall = b.d_stall;
-    ctl.move_index = m;
-    ctl.expected_ties = m > 0 ? reinterpret_cast<const uint32_t*>(b.d_in + b.o_expect) : nullptr;
-    ctl.actions = reinterpret_cast<int32_t*>(out + b.o_actions);
-    ctl.visits = reinterpret_cast<int32_t*>(out + b.o_visits);
-    ctl.root_value_sum = reinterpret_cast<double*>(out + b.o_rvs);
-    ctl.root_predicted = reinterpret_cast<float*>(out + b.o_pred);
-    ctl.max_depth = reinterpret_cast<int32_t*>(out + b.o_depth);
-    ctl.tie_words = reinterpret_cast<uint32_t*>(out + b.o_ties);
-    ctl.sample_words = reinterpret_cast<uint32_t*>(out + b.o_sample);
-    ctl.depth_sum = reinterpret_cast<int32_t*>(out + b.o_dsum);
-    int rc = launch_fused_move(eng, observations, ctl, true, stream);
-    if (rc) return rc;
-    b.enqueued = m + 1;
-    return MZMCTS_OK;
-}
-
-const int32_t* mzmcts_moves_actions(mzmcts_engine* eng, int32_t move) {
-    if (!eng || !eng->batch.in_flight || move < 0 || move >= eng->batch.set[eng->batch.cur].n_moves) return nullptr;
-    return reinterpret_cast<const int32_t*>(eng->batch.d_out + eng->batch.out_stride * static_cast<size_t>(move) +
-                                            eng->batch.o_actions);
-}
-
-int mzmcts_moves_ring(mzmcts_engine* eng, void** host_base, int64_t* move_stride, int64_t* offsets, int32_t* capacity) {
-    if (!eng || !host_base || !move_stride || !offsets || !capacity) return MZMCTS_ERR_INVALID;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (!b.h_out) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_ring: no batch has been prepared yet");
-    *host_base = b.h_out;
-    *move_stride = static_cast<int64_t>(b.out_stride);
-    *capacity = b.capacity;
-    offsets[0] = static_cast<int64_t>(b.o_actions);
-    offsets[1] = static_cast<int64_t>(b.o_visits);
-    offsets[2] = static_cast<int64_t>(b.o_rvs);
-    offsets[3] = static_cast<int64_t>(b.o_pred);
-    offsets[4] = static_cast<int64_t>(b.o_depth);
-    return MZMCTS_OK;
-}
-
-int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actions, int32_t* visits, double* root_value_sum,
-                         float* root_predicted, int32_t* max_depth, void* stream_) {
-    if (!eng) return MZMCTS_ERR_INVALID;
-    mzmcts_engine::MoveBatch& b = eng->batch;
-    if (!b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_collect: no batch in flight");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int E = eng->p.E, A = eng->p.A, M = b.enqueued;
-    const bool trace = std::getenv("MZMCTS_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = trace ? now() : 0.0;
-    MZ_HIP(eng, hipEventRecord(b.done, stream));
-    MZ_HIP(eng, hipEventSynchronize(b.done));
-    const double t_kernels = trace ? now() : 0.0;
-    if (M > 0) MZ_HIP(eng, hipMemcpyAsync(b.h_out, b.d_out, b.out_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, eng->p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    MZ_HIP(eng, hipEventRecord(b.done, stream));
-    MZ_HIP(eng, hipEventSynchronize(b.done));
-    const double t_copied = trace ? now() : 0.0;
-    b.in_flight = false;
-    ChainSet& c = b.set[b.cur];
-    ChainSet& next = b.set[b.cur ^ 1];
-    if (eng->h_error_flag[0] != 0)
-        return fail(eng, MZMCTS_ERR_INVALID, (eng->h_error_flag[0] & 8) ? "device error flag set: unexpected DPP lane mapping"
-                                             : (eng->h_error_flag[0] & 2)
-                                                 ? "device error flag set: tree links are inconsistent"
-                                                 : "device error flag set: a UCB score was NaN (no maximum to select)");
-    auto block = [&](int m, size_t off) { return b.h_out + b.out_stride * static_cast<size_t>(m) + off; };
-    ChainSet* sets[2] = {&c, next.drawn ? &next : nullptr};
-    std::atomic<int64_t> played_total{0}, depth_total{0};
-    eng->for_each_env([&](int lo, int hi) {
-        int64_t local = 0, local_depth = 0;
-        for (int e = lo; e < hi; ++e) {
-            const bool active = c.nlegal[e] > 0;
-            int k = 0;  // moves of this env that were searched: the first k of the batch
-            if (active) {
-                // played moves are a prefix of the batch (a stall is sticky, a move limit is a prefix): if the last
-                // one ran, all of them did -- one read instead of M for nearly every env
-                if (M > 0 && reinterpret_cast<const int32_t*>(block(M - 1, b.o_actions))[e] >= 0)
-                    k = M;
-                else
-                    while (k < M && reinterpret_cast<const int32_t*>(block(k, b.o_actions))[e] >= 0) ++k;
-            }
-            if (moves_done) moves_done[e] = k;
-            const bool per_move = actions || visits || root_value_sum || root_predicted || max_depth || eng->profiling;
-            for (int m = 0; per_move && m < M; ++m) {
-                const bool live = m < k;
-                const size_t me = static_cast<size_t>(m) * E + e;
-                if (actions) actions[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_actions))[e] : -1;
-                if (visits)
-                    for (int i = 0; i < A; ++i)
-                        visits[me * A + i] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_visits))[static_cast<size_t>(e) * A + i] : 0;
-                if (root_value_sum) root_value_sum[me] = live ? reinterpret_cast<const double*>(block(m, b.o_rvs))[e] : 0.0;
-                if (root_predicted) root_predicted[me] = live ? reinterpret_cast<const float*>(block(m, b.o_pred))[e] : 0.f;
-                if (max_depth) max_depth[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_depth))[e] : 0;
-                if (live && eng->profiling) local_depth += reinterpret_cast<const int32_t*>(block(m, b.o_dsum))[e];
-            }
-            local += k;
-            // The mirror ran ahead over this batch (and over the next one, if it is pre-drawn): put it where the
-            // device copy really is, unless everything went as the draws assumed.
-            mz::HostStream& s = eng->streams[e];
-            bool redraw_next = next.drawn && next.deferred[e];
-            if (active) {
-                if (k == 0) {  // nothing was searched (batch collected before its first move ran): undo every draw
-                    restore_stream(eng, e, c.start[e], sets, 2);
-                    // (rows drawn on top of a running batch start before that batch's last tie-break / sampling
-                    // words, which its collect() has confirmed since: step over them again)
-                    s.skip(static_cast<uint64_t>(c.tail_ties[e]) + c.tail_sample[e]);
-                    eng->lag[e] = (c.tail_ties[e] | c.tail_sample[e]) ? 0u : c.start_lag[e];
-                    redraw_next = next.drawn;
-                } else {
-                    const uint32_t ties = reinterpret_cast<const uint32_t*>(block(k - 1, b.o_ties))[e];
-                    const uint32_t sampled = reinterpret_cast<const uint32_t*>(block(k - 1, b.o_sample))[e];
-                    const bool as_assumed = next.drawn && !next.deferred[e] && next.nlegal[e] > 0 && k == c.n_moves &&
-                                            ties == next.tail_ties[e] && sampled == next.tail_sample[e];
-                    if (!as_assumed) {
-                        const MoveRecord& r = c.rec[static_cast<size_t>(k - 1) * E + e];
-                        if (s.words != r.words) restore_stream(eng, e, r, sets, 2);
-                        s.skip(ties);
-                        s.skip(sampled);
-                        eng->lag[e] = 0;
-                        redraw_next = next.drawn;
-                    }
-                }
-            } else if (next.drawn && next.nlegal[e] > 0 && !next.deferred[e]) {
-                redraw_next = false;  // inactive here, active next: drawn from the exact state already
-            }
-            if (redraw_next) draw_env_rows(eng, next, e, false, nullptr);
-        }
-        played_total.fetch_add(local, std::memory_order_relaxed);
-        depth_total.fetch_add(local_depth, std::memory_order_relaxed);
-    });
-    c.drawn = false;
-    if (trace)
-        std::fprintf(stderr, "[mzmcts] moves_collect M=%d: wait for kernels %.1f us, download %.1f us, reconcile %.1f us\n", M,
-                     t_kernels - t_begin, t_copied - t_kernels, now() - t_copied);
-    eng->prof.simulations += played_total.load() * eng->p.S;
-    eng->prof.select_depth_sum += depth_total.load();
-    return MZMCTS_OK;
-}
 
 #ifdef MZ_STAMPS
 // diagnostic build only: per-phase cycle sums of the fused kernel (see tools/stamp_fused.py)
@@ -1712,261 +903,4 @@ int mzmcts_get_profile(mzmcts_engine* eng, mzmcts_profile* out, int32_t reset) {
 }
 
 int64_t mzmcts_device_bytes(const mzmcts_engine* eng) { return eng ? eng->device_bytes : 0; }
-
-// ---- stand-alone host streams ----------------------------------------------------------------------
-struct mzmcts_rng {
-    mz::HostStream s;
-};
-
-mzmcts_rng* mzmcts_rng_create(uint32_t seed) {
-    auto* r = new mzmcts_rng();
-    r->s.seed(seed);
-    return r;
-}
-void mzmcts_rng_destroy(mzmcts_rng* r) { delete r; }
-void mzmcts_rng_reseed(mzmcts_rng* r, uint32_t seed) { r->s.seed(seed); }
-uint32_t mzmcts_rng_next_u32(mzmcts_rng* r) { return r->s.u32(); }
-double mzmcts_rng_random_sample(mzmcts_rng* r) { return r->s.uniform(); }
-uint32_t mzmcts_rng_choice(mzmcts_rng* r, uint32_t n) { return r->s.below(n); }
-int32_t mzmcts_rng_choice_p(mzmcts_rng* r, const double* p, int32_t n) { return r->s.choice_p(p, n); }
-void mzmcts_rng_choice_p_many(mzmcts_rng* r, const double* p, int32_t n, int32_t count, int32_t* out) {
-    for (int32_t i = 0; i < count; ++i) out[i] = r->s.choice_p(p, n);
-}
-int32_t mzmcts_rng_choice_priorities(mzmcts_rng* r, const float* priorities, int32_t n, float* prob_out) {
-    // position_probs = priorities / sum(priorities): a left-to-right float32 sum (Python's sum over float32
-    // scalars), a float32 division per entry, then RandomState.choice(n, p=position_probs)
-    float total = 0.f;
-    for (int32_t i = 0; i < n; ++i) total = total + priorities[i];
-    std::vector<double> p(static_cast<size_t>(n));
-    for (int32_t i = 0; i < n; ++i) p[i] = static_cast<double>(priorities[i] / total);
-    const int32_t idx = r->s.choice_p(p.data(), n);
-    if (prob_out && idx >= 0 && idx < n) *prob_out = priorities[idx] / total;
-    return idx;
-}
-void mzmcts_rng_dirichlet(mzmcts_rng* r, double alpha, int32_t k, double* out) { r->s.dirichlet(alpha, k, out); }
-void mzmcts_rng_export(const mzmcts_rng* r, uint32_t* key, int32_t* pos, int32_t* has_gauss, double* cached) {
-    std::memcpy(key, r->s.key, sizeof(r->s.key));
-    *pos = r->s.pos;
-    *has_gauss = r->s.has_gauss;
-    *cached = r->s.gauss;
-}
-void mzmcts_rng_import(mzmcts_rng* r, const uint32_t* key, int32_t pos, int32_t has_gauss, double cached) {
-    std::memcpy(r->s.key, key, sizeof(r->s.key));
-    r->s.pos = pos;
-    r->s.has_gauss = has_gauss;
-    r->s.gauss = cached;
-}
-int32_t mzmcts_rng_select_action(mzmcts_rng* r, const int32_t* visits, int32_t n, double temperature) {
-    return r->s.select_action(visits, n, temperature);
-}
-
-}  // extern "C"
-
-
-// ---- game-history filer (include/mzhist.h) ---------------------------------------------------------------------
-struct mzhist {
-    int E = 0, L = 0, obs = 0, A = 0;
-    std::string error;
-    // running games, one row per env
-    std::vector<float> observations;   // [E][L+1][obs]
-    std::vector<int32_t> actions;      // [E][L+1]
-    std::vector<float> rewards;        // [E][L+1]
-    std::vector<int32_t> to_play;      // [E][L+1]
-    std::vector<double> child_visits;  // [E][L][A]
-    std::vector<double> root_values;   // [E][L]
-    std::vector<int32_t> length;       // [E]
-    // games finished by the last mzhist_file
-    std::vector<int32_t> fin_env, fin_length, fin_actions, fin_to_play, fin_count, fin_offset;
-    std::vector<float> fin_observations, fin_rewards;
-    std::vector<double> fin_child_visits, fin_root_values;
-    int fin_n = 0, fin_row = 0;
-};
-
-extern "C" {
-
-const char* mzhist_last_error(const mzhist* h) { return h ? h->error.c_str() : "mzhist: null handle"; }
-
-int mzhist_create(int32_t num_envs, int32_t max_moves, int32_t obs_floats, int32_t num_actions, mzhist** out) {
-    if (!out || num_envs <= 0 || max_moves <= 0 || obs_floats <= 0 || num_actions <= 0) return -1;
-    mzhist* h = new mzhist();
-    h->E = num_envs;
-    h->L = max_moves;
-    h->obs = obs_floats;
-    h->A = num_actions;
-    const size_t E = num_envs, L = max_moves;
-    h->observations.assign(E * (L + 1) * obs_floats, 0.f);
-    h->actions.assign(E * (L + 1), 0);
-    h->rewards.assign(E * (L + 1), 0.f);
-    h->to_play.assign(E * (L + 1), 0);
-    h->child_visits.assign(E * L * num_actions, 0.0);
-    h->root_values.assign(E * L, 0.0);
-    h->length.assign(E, 0);
-    h->fin_count.assign(E, 0);
-    h->fin_offset.assign(E + 1, 0);
-    *out = h;
-    return 0;
-}
-
-void mzhist_destroy(mzhist* h) { delete h; }
-
-const int32_t* mzhist_lengths(const mzhist* h) { return h ? h->length.data() : nullptr; }
-
-int mzhist_begin(mzhist* h, const float* first_observations, const int32_t* first_to_play) {
-    if (!h || !first_observations) return -1;
-    const size_t L1 = static_cast<size_t>(h->L) + 1;
-    for (int e = 0; e < h->E; ++e) {
-        std::memcpy(h->observations.data() + static_cast<size_t>(e) * L1 * h->obs,
-                    first_observations + static_cast<size_t>(e) * h->obs, sizeof(float) * h->obs);
-        h->actions[e * L1] = 0;
-        h->rewards[e * L1] = 0.f;
-        h->to_play[e * L1] = first_to_play ? first_to_play[e] : 0;
-        h->length[e] = 0;
-    }
-    return 0;
-}
-
-int mzhist_rows(mzhist* h, float* observations, int32_t* actions, float* rewards, int32_t* to_play, double* child_visits,
-                double* root_values, int32_t* lengths, int32_t load) {
-    if (!h || !observations || !actions || !rewards || !to_play || !child_visits || !root_values || !lengths) return -1;
-    auto move = [&](auto& mine, auto* theirs) {
-        if (load)
-            std::memcpy(mine.data(), theirs, sizeof(mine[0]) * mine.size());
-        else
-            std::memcpy(theirs, mine.data(), sizeof(mine[0]) * mine.size());
-    };
-    move(h->observations, observations);
-    move(h->actions, actions);
-    move(h->rewards, rewards);
-    move(h->to_play, to_play);
-    move(h->child_visits, child_visits);
-    move(h->root_values, root_values);
-    move(h->length, lengths);
-    return 0;
-}
-
-int mzhist_file(mzhist* h, const mzhist_moves* mv, int32_t* n_finished) {
-    if (!h || !mv || !mv->moves_done || !mv->actions || !mv->visits || !mv->root_value_sum || !mv->legal || !mv->num_legal ||
-        !mv->rewards || !mv->done || !mv->obs_after || !mv->obs_next) {
-        if (h) h->error = "mzhist_file: null argument";
-        return -1;
-    }
-    const int E = h->E, A = h->A, M = mv->n_moves, obs = h->obs;
-    const size_t L = h->L, L1 = L + 1;
-    const double S = static_cast<double>(mv->num_simulations);
-    auto at = [](const void* base, int64_t stride, int m) { return static_cast<const uint8_t*>(base) + stride * m; };
-    WorkerPool& pool = shared_pool();
-    auto for_envs = [&](const std::function<void(int, int)>& body) {
-        if (pool.size() > 0 && E >= 512)
-            pool.run(E, body);
-        else
-            body(0, E);
-    };
-    // pass 1: how many games end per env, and how long the longest of them is
-    std::atomic<int> longest{0};
-    std::atomic<bool> overflow{false};
-    for_envs([&](int lo, int hi) {
-        int local_longest = 0;
-        for (int e = lo; e < hi; ++e) {
-            int len = h->length[e], count = 0;
-            const int k = std::min(mv->moves_done[e], M);
-            for (int m = 0; m < k; ++m) {
-                ++len;
-                if (len > h->L) overflow.store(true);
-                if (mv->done[static_cast<size_t>(m) * E + e]) {
-                    ++count;
-                    local_longest = std::max(local_longest, len);
-                    len = 0;
-                }
-            }
-            h->fin_count[e] = count;
-        }
-        int seen = longest.load();
-        while (local_longest > seen && !longest.compare_exchange_weak(seen, local_longest)) {
-        }
-    });
-    if (overflow.load()) {
-        h->error = "mzhist_file: a game outgrew max_moves";
-        return -1;
-    }
-    h->fin_offset[0] = 0;
-    for (int e = 0; e < E; ++e) h->fin_offset[e + 1] = h->fin_offset[e] + h->fin_count[e];
-    const int n = h->fin_offset[E];
-    const size_t W = static_cast<size_t>(longest.load()), W1 = W + 1;
-    h->fin_n = n;
-    h->fin_row = static_cast<int>(W);
-    h->fin_env.resize(n);
-    h->fin_length.resize(n);
-    h->fin_observations.resize(static_cast<size_t>(n) * W1 * obs);
-    h->fin_actions.resize(static_cast<size_t>(n) * W1);
-    h->fin_rewards.resize(static_cast<size_t>(n) * W1);
-    h->fin_to_play.resize(static_cast<size_t>(n) * W1);
-    h->fin_child_visits.resize(static_cast<size_t>(n) * W * A);
-    h->fin_root_values.resize(static_cast<size_t>(n) * W);
-    // pass 2: append the moves; copy a row out when its game ends and start the next game in place
-    for_envs([&](int lo, int hi) {
-        for (int e = lo; e < hi; ++e) {
-            float* row_obs = h->observations.data() + static_cast<size_t>(e) * L1 * obs;
-            int32_t* row_act = h->actions.data() + static_cast<size_t>(e) * L1;
-            float* row_rew = h->rewards.data() + static_cast<size_t>(e) * L1;
-            int32_t* row_tp = h->to_play.data() + static_cast<size_t>(e) * L1;
-            double* row_cv = h->child_visits.data() + static_cast<size_t>(e) * L * A;
-            double* row_rv = h->root_values.data() + static_cast<size_t>(e) * L;
-            const int32_t* legal = mv->legal + static_cast<size_t>(e) * A;
-            const int n_legal = mv->num_legal[e];
-            int len = h->length[e];
-            int out_slot = h->fin_offset[e];
-            const int k = std::min(mv->moves_done[e], M);
-            for (int m = 0; m < k; ++m) {
-                const size_t me = static_cast<size_t>(m) * E + e;
-                const int32_t* visits = reinterpret_cast<const int32_t*>(at(mv->visits, mv->visits_stride, m)) + static_cast<size_t>(e) * A;
-                double* cv = row_cv + static_cast<size_t>(len) * A;
-                for (int a = 0; a < A; ++a) cv[a] = 0.0;
-                for (int i = 0; i < n_legal; ++i) cv[legal[i]] = static_cast<double>(visits[i]) / S;
-                row_rv[len] = reinterpret_cast<const double*>(at(mv->root_value_sum, mv->root_value_sum_stride, m))[e] / S;
-                row_act[len + 1] = reinterpret_cast<const int32_t*>(at(mv->actions, mv->actions_stride, m))[e];
-                row_rew[len + 1] = mv->rewards[me];
-                std::memcpy(row_obs + static_cast<size_t>(len + 1) * obs, mv->obs_after + me * obs, sizeof(float) * obs);
-                row_tp[len + 1] = mv->to_play_after ? mv->to_play_after[me] : 0;
-                ++len;
-                if (mv->done[me]) {
-                    const size_t o = static_cast<size_t>(out_slot);
-                    h->fin_env[o] = e;
-                    h->fin_length[o] = len;
-                    std::memcpy(h->fin_observations.data() + o * W1 * obs, row_obs, sizeof(float) * (len + 1) * obs);
-                    std::memcpy(h->fin_actions.data() + o * W1, row_act, sizeof(int32_t) * (len + 1));
-                    std::memcpy(h->fin_rewards.data() + o * W1, row_rew, sizeof(float) * (len + 1));
-                    std::memcpy(h->fin_to_play.data() + o * W1, row_tp, sizeof(int32_t) * (len + 1));
-                    std::memcpy(h->fin_child_visits.data() + o * W * A, row_cv, sizeof(double) * len * A);
-                    std::memcpy(h->fin_root_values.data() + o * W, row_rv, sizeof(double) * len);
-                    ++out_slot;
-                    len = 0;
-                    std::memcpy(row_obs, mv->obs_next + me * obs, sizeof(float) * obs);  // the reset observation
-                    row_act[0] = 0;
-                    row_rew[0] = 0.f;
-                    row_tp[0] = mv->to_play_next ? mv->to_play_next[me] : 0;
-                }
-            }
-            h->length[e] = len;
-        }
-    });
-    if (n_finished) *n_finished = n;
-    return 0;
-}
-
-int mzhist_finished(mzhist* h, const int32_t** env_index, const int32_t** length, const float** observations,
-                    const int32_t** actions, const float** rewards, const int32_t** to_play, const double** child_visits,
-                    const double** root_values, int32_t* row_moves) {
-    if (!h) return -1;
-    if (env_index) *env_index = h->fin_env.data();
-    if (length) *length = h->fin_length.data();
-    if (observations) *observations = h->fin_observations.data();
-    if (actions) *actions = h->fin_actions.data();
-    if (rewards) *rewards = h->fin_rewards.data();
-    if (to_play) *to_play = h->fin_to_play.data();
-    if (child_visits) *child_visits = h->fin_child_visits.data();
-    if (root_values) *root_values = h->fin_root_values.data();
-    if (row_moves) *row_moves = h->fin_row;
-    return h->fin_n;
-}
-
 }  // extern "C"

@@ -235,9 +235,7 @@ class MCTS:
             override_root_with=None):
         """Search from `observation`; returns (root Node, {"max_tree_depth", "root_predicted_value"})."""
         if override_root_with:
-            raise NotImplementedError(
-                "override_root_with is not supported by the device engine: trees live in HIP pools and "
-                "are rebuilt per search (the reference itself only uses it from diagnose_model.py)")
+            return self._run_from_root(model, override_root_with, add_exploration_noise)
         device = next(model.parameters()).device
         if device.type != "cuda":
             raise RuntimeError("MCTS.run needs the model on a HIP device; the engine has no CPU fallback")
@@ -256,6 +254,37 @@ class MCTS:
             "root_predicted_value": float(stats["root_predicted_value"][0]),
         }
         return root, extra_info
+
+    def _run_from_root(self, model, root_in, add_exploration_noise):
+        """`run(..., override_root_with=root)` (self_play.py:276-278; diagnose_model.py builds such roots with
+        Node(0).expand(...)): the given root's children (priors), reward, to_play and hidden state are uploaded as the
+        search's root instead of being computed from an observation; root_predicted_value is None as in the reference.
+        The root must be freshly expanded -- trees are rebuilt in the device pools per search, so visit counts of an
+        earlier search cannot be continued."""
+        if not root_in.expanded() or root_in.hidden_state is None:
+            raise AssertionError("override_root_with must be an expanded node carrying a hidden state")
+        if root_in.visit_count or any(c.visit_count or c.expanded() for c in root_in.children.values()):
+            raise NotImplementedError("override_root_with: only a freshly expanded root (no visits yet) can be uploaded "
+                                      "to the device engine")
+        device = next(model.parameters()).device
+        if device.type != "cuda":
+            raise RuntimeError("MCTS.run needs the model on a HIP device; the engine has no CPU fallback")
+        legal_actions = list(root_in.children.keys())
+        assert set(legal_actions).issubset(set(self.config.action_space)), (
+            "Legal actions should be a subset of the action space.")
+        engine = self._get_engine(device, model)
+        engine.set_rng_state(0, numpy.random.get_state())
+        priors = numpy.zeros((1, engine.A), dtype=numpy.float64)
+        priors[0, : len(legal_actions)] = [root_in.children[a].prior for a in legal_actions]
+        with torch.no_grad(), torch.cuda.device(engine.device):
+            engine.begin_search([legal_actions], [root_in.to_play], add_exploration_noise)
+            engine.expand_roots_injected(numpy.array([float(root_in.reward)]), priors)
+            engine.pool[0, 0].copy_(torch.as_tensor(root_in.hidden_state).to(engine.device, torch.float32).reshape(-1))
+            engine._run_simulations(model)
+            stats = engine.readout()
+        numpy.random.set_state(engine.get_rng_state(0))
+        root = Node._from_engine(engine, legal_actions, root_in.to_play, len(self.config.players))
+        return root, {"max_tree_depth": int(stats["max_tree_depth"][0]), "root_predicted_value": None}
 
     def select_child(self, node, min_max_stats):
         """Child with the highest UCB score, ties broken like the reference (self_play.py:364-379)."""

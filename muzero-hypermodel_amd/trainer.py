@@ -62,6 +62,8 @@ class Trainer:
             if self.training_step % self.config.checkpoint_interval == 0:
                 shared_storage.set_info({"weights": copy.deepcopy(self.model.get_weights()),
                                          "optimizer_state": copy.deepcopy(models.dict_to_cpu(self.optimizer.state_dict()))})
+                if self.config.save_model:               # trainer.py:96-97
+                    shared_storage.save_checkpoint()
             shared_storage.set_info({"training_step": self.training_step, "lr": self.optimizer.param_groups[0]["lr"],
                                      "total_loss": total_loss, "value_loss": value_loss, "reward_loss": reward_loss,
                                      "policy_loss": policy_loss})

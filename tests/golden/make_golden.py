@@ -807,6 +807,45 @@ def g14_trainer(ctx):
     save("g14_trainer_cartpole", **out)
 
 
+def g16_trainer_resnet(ctx):
+    """The same two Trainer steps on the TicTacToe residual network (BatchNorm in train(), 3x3 and 1x1 convolutions,
+    two players): pins the training forward / backward of the residual modules (models.py:206-522, trainer.py:124-298)."""
+    import copy
+    import replay_buffer
+    import trainer
+    self_play, cfgs = ctx["self_play"], ctx["configs"]
+    config = copy.deepcopy(cfgs["tictactoe"])
+    config.batch_size = 24
+    config.train_on_gpu = False
+    rs = numpy.random.RandomState(2718)
+    lengths = [int(v) for v in rs.randint(3, 10, 14)]
+    games = [_synthetic_history(self_play, rs, config, n) for n in lengths]
+    for gh in games:                       # board-like observations
+        gh.observation_history = [numpy.sign(o).astype("float32") for o in gh.observation_history]
+    rb = replay_buffer.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
+    for gh in games:
+        rb.save_game(gh)
+    index_batch, batch = rb.get_batch()
+    template = ctx["models"].MuZeroNetwork(config).state_dict()
+    weights = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(template, 0).items()}
+    tr = trainer.Trainer({"weights": copy.deepcopy(weights), "training_step": 0, "optimizer_state": None}, config)
+    out = dict(config_scalars(config))
+    obs_b, act_b, val_b, rew_b, pol_b, w_b, gs_b = batch
+    out.update(observation_batch=numpy.array(obs_b, dtype="float32"), action_batch=numpy.array(act_b, dtype="int64"),
+               value_batch=numpy.array(val_b, dtype="float64"), reward_batch=numpy.array(rew_b, dtype="float64"),
+               policy_batch=numpy.array(pol_b, dtype="float64"), weight_batch=numpy.array(w_b, dtype="float32"),
+               gradient_scale_batch=numpy.array(gs_b, dtype="float64"))
+    for step in range(2):
+        tr.update_lr()
+        out[f"lr{step}"] = tr.optimizer.param_groups[0]["lr"]
+        priorities, total, v, r, p = tr.update_weights(batch)
+        out[f"priorities{step}"] = numpy.asarray(priorities, dtype="float32")
+        out[f"losses{step}"] = numpy.array([total, v, r, p], dtype="float64")
+    for k, t in tr.model.get_weights().items():          # weights (and BatchNorm running statistics) after both steps
+        out[f"w1_{k}"] = t.detach().cpu().numpy().copy()
+    save("g16_trainer_tictactoe", **out)
+
+
 class _LoopStorage:
     """Fake shared_storage / replay_buffer for the continuous_self_play fixture: every call is logged; the
     training step advances by `step_per_game` whenever a game is saved or a test result is stored, so the loop ends."""
@@ -941,7 +980,7 @@ def make_configs():
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
        g5_tictactoe, g5_connect4, g5_atari84, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
-       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer, g15_self_play_loop]
+       g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer, g15_self_play_loop, g16_trainer_resnet]
 
 
 def main():

@@ -62,3 +62,86 @@ def test_trainer_publishes_into_flat_weights(pkg):
     tr.publish(flat)
     for k, t in tr.model.get_weights().items():
         assert torch.equal(actor_model.state_dict()[k], t), k
+
+
+def test_resnet_trainer_matches_reference_on_cpu(pkg):
+    """Fixture G16: two Trainer steps on the TicTacToe residual network (BatchNorm batch statistics, 3x3 / 1x1
+    convolution forward and backward of this package's modules, two-player targets) against the reference's."""
+    from synth import synthetic_state_dict
+    fx = load_golden("g16_trainer_tictactoe")
+    tr_mod = importlib.import_module("muzero-hypermodel_amd.trainer")
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    config.batch_size = 24
+    template = models.MuZeroNetwork(config).state_dict()
+    weights = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(template, 0).items()}
+    for as_tensors in (False, True):
+        tr = tr_mod.Trainer({"weights": {k: v.clone() for k, v in weights.items()}, "training_step": 0,
+                             "optimizer_state": None}, config, device="cpu")
+        for step in range(2):
+            tr.update_lr()
+            assert tr.optimizer.param_groups[0]["lr"] == float(fx[f"lr{step}"])
+            priorities, total, v, r, p = tr.update_weights(batch_of(fx, as_tensors))
+            # step 0 = the training-mode forward of identical weights: equal to fp32 rounding.  Step 1 runs on weights one
+            # Adam step apart: that step is lr * g / (|g| + eps) ~ +-lr for ANY non-zero gradient, so entries whose
+            # gradient is zero up to the rounding of a different (but equivalent) backward kernel move by up to 2 lr
+            tol = 2e-6 if step == 0 else 3e-3
+            np.testing.assert_allclose([total, v, r, p], fx[f"losses{step}"], rtol=tol, atol=tol)
+            if step == 0:
+                np.testing.assert_allclose(priorities, fx[f"priorities{step}"], rtol=2e-5, atol=2e-5)
+            else:                                        # (decoded values amplify the flipped steps ~100x: most entries only)
+                assert np.isclose(priorities, fx[f"priorities{step}"], rtol=0.05, atol=0.05).mean() >= 0.9
+        for k, t in tr.model.get_weights().items():
+            got = t.detach().cpu().numpy()
+            want = fx[f"w1_{k}"]
+            if got.dtype.kind == "f":
+                # Two Adam steps moved every weight by ~2 lr.  A backward pass that sums in another order than the
+                # reference's leaves gradients equal to rounding; Adam's first steps (lr * g / (|g| + eps)) turn the ones
+                # that are zero up to rounding into +-lr, so a few entries sit up to two steps apart while the tensor as
+                # a whole follows the reference's update to within a tenth of its size (measured: up to 3 %).
+                moved = np.abs(want - weights[k].numpy()).mean()
+                assert np.abs(got - want).mean() <= 0.1 * moved + 1e-7, (k, np.abs(got - want).mean(), moved)
+                if "running_" not in k:
+                    assert np.abs(got - want).max() <= 4.5 * config.lr_init, k
+            else:
+                assert np.array_equal(got, want), k
+
+
+def test_continuous_update_weights_publishes_and_checkpoints(pkg):
+    """The trainer loop's storage protocol (trainer.py:61-121): weights + optimizer state every checkpoint_interval
+    steps, save_checkpoint() right after when config.save_model, the per-step metrics dictionary, PER priorities."""
+    fx = load_golden("g14_trainer_cartpole")
+    tr_mod = importlib.import_module("muzero-hypermodel_amd.trainer")
+    config = importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
+    config.batch_size, config.checkpoint_interval, config.save_model, config.training_steps = 32, 2, True, 4
+    config.ratio, config.training_delay = None, 0
+    w = load_golden("cartpole_weights")
+    weights = {k: torch.from_numpy(w[k]) for k in w.files}
+    tr = tr_mod.Trainer({"weights": weights, "training_step": 0, "optimizer_state": None}, config, device="cpu")
+    log = []
+
+    class Storage:
+        info = {"num_played_games": 1, "terminate": False, "num_played_steps": 10}
+
+        def get_info(self, key):
+            return self.info[key]
+
+        def set_info(self, keys, values=None):
+            log.append(("set_info", tuple(sorted(keys))))
+
+        def save_checkpoint(self):
+            log.append(("save_checkpoint",))
+
+    class Replay:
+        def get_batch(self):
+            return list(range(32)), batch_of(fx, True)
+
+        def update_priorities(self, priorities, index_batch):
+            log.append(("update_priorities", len(index_batch), np.asarray(priorities).shape))
+    tr.continuous_update_weights(Replay(), Storage())
+    metrics = ("set_info", ("lr", "policy_loss", "reward_loss", "total_loss", "training_step", "value_loss"))
+    publish = ("set_info", ("optimizer_state", "weights"))
+    prio = ("update_priorities", 32, (32, config.num_unroll_steps + 1))
+    assert log == [prio, metrics, prio, publish, ("save_checkpoint",), metrics, prio, metrics, prio, publish,
+                   ("save_checkpoint",), metrics]
+    assert tr.training_step == 4
