@@ -351,6 +351,23 @@ int mzmcts_board_conv3x3(const float *x, const float *packed, const float *scale
                          const float *residual, float *out, int64_t batch, int32_t cin, int32_t cout, int32_t height,
                          int32_t width, int32_t relu, void *stream);
 
+/* A whole tower of such layers in ONE launch, activations resident in LDS from layer to layer (csrc/board_conv.hip):
+ * layer 0 reads x dev f32[batch, cin0, height, width]; every layer produces `channels` planes; `skip` adds the input of
+ * the layer BEFORE (the residual block's input, models.py:226-229) ahead of the ReLU.  export_raw / export_unit (either
+ * may be NULL) receive the layer's output as NCHW dev f32[batch, channels, height, width], export_unit after the
+ * per-plane min-max rescale of models.py:525-549 (which then also replaces the output for the following layers):
+ *   dynamics    conv(C+1 -> C), N residual blocks; last layer: export_raw -> reward head, export_unit -> next state
+ *   prediction  N residual blocks; last layer: export_raw -> value / policy heads
+ * (models.py:399-420, 500-522, 586-602).  n_layers <= 16; shapes as mzmcts_board_conv_supported; MZMCTS_ERR_INVALID
+ * when two activation buffers of the workgroup do not fit in LDS (the caller keeps the per-layer path). */
+typedef struct mzmcts_tower_layer {
+    const float *packed, *scale, *shift;
+    float *export_raw, *export_unit;
+    int32_t cin, relu, skip, reserved;
+} mzmcts_tower_layer;
+int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
+                       const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */

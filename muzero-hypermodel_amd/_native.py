@@ -110,6 +110,7 @@ PROTOTYPES = {
     "mzmcts_board_conv_pack": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
     "mzmcts_board_conv3x3": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void]),
+    "mzmcts_board_tower": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
     "mzenv_advance": (ctypes.c_int, [c_void] * 10),
@@ -282,6 +283,13 @@ class HostRng:
         key = np.ascontiguousarray(state[1], dtype=np.uint32)
         self._lib.mzmcts_rng_import(self._h, ptr(key, c_u32_p), int(state[2]), int(state[3]),
                                     float(state[4]))
+
+
+class MzTowerLayer(ctypes.Structure):
+    """include/mzmcts.h mzmcts_tower_layer"""
+    _fields_ = [("packed", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+                ("export_raw", ctypes.c_void_p), ("export_unit", ctypes.c_void_p), ("cin", ctypes.c_int32),
+                ("relu", ctypes.c_int32), ("skip", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 def exact_inverse_temperature(temperature):

@@ -247,6 +247,260 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_conv3x3_kernel(const fl
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// A whole tower of such convolutions in ONE launch: the activations of the workgroup's SB samples stay in LDS from layer
+// to layer (two padded-plane buffers, a layer reads one and writes the other), so only the tower's input is read from
+// HBM and only the tensors a later launch needs are written back:
+//     dynamics   conv(C+1 -> C) -> N x ResidualBlock -> [raw state -> reward head] -> min-max rescale -> next state
+//     prediction N x ResidualBlock -> [features -> value / policy heads]
+// (reference models.py:399-420 DynamicsNetwork.forward, 586-602 the rescale in MuZeroResidualNetwork.dynamics, 500-522
+// PredictionNetwork.forward).  A residual block is two layers: conv1 reads the block's input x from buffer U and writes
+// V; conv2 reads V and writes relu(conv * scale + shift + x) over x in U (every element is read and written by the one
+// lane that owns it).  Per layer the same exact-fp32 MFMA main loop as board_conv3x3_kernel.
+// -------------------------------------------------------------------------------------------------------------------
+struct TowerLayer {
+    const float* wt;        // packed weights (mzmcts_board_conv_pack)
+    const float* scale;     // folded batch norm
+    const float* shift;
+    float* export_raw;      // NCHW [batch, C, H, W] copy of this layer's output, or null
+    float* export_unit;     // the same after the per-plane min-max rescale (which then also replaces it in LDS), or null
+    int32_t cin;
+    int32_t relu;
+    int32_t skip;           // add the destination buffer's previous content (the residual block's input) before the ReLU
+    int32_t pad;
+};
+constexpr int kMaxTowerLayers = 16;
+struct TowerArgs {
+    TowerLayer layer[kMaxTowerLayers];
+    int32_t n_layers;
+};
+
+template <int NT, int H, int W, int SB>
+__global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const float* __restrict__ x, int batch, int cin0,
+                                                                       uint32_t cin0_magic, int cp0, int cp1,
+                                                                       TowerArgs args) {
+    constexpr int P = H * W;
+    constexpr int PW = W + 1;
+    constexpr int PP = (H + 2) * PW + 1;
+    constexpr int ROWS = SB * P;
+    constexpr int MT = (ROWS + 15) / 16;
+    constexpr int RG = kConvWaves / NT;
+    constexpr int MTW = (MT + RG - 1) / RG;
+    constexpr int COUT = 16 * NT;
+    constexpr int THREADS = 64 * kConvWaves;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // buffer 0: [SB][PP][cp0] | buffer 1: [SB][PP][cp1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b0 = blockIdx.x * SB;
+    const int n_samples = min(SB, batch - b0);
+    float* const buf[2] = {lds, lds + SB * PP * cp0};
+    const int cps[2] = {cp0, cp1};
+
+    // ---- zero both buffers (borders, padding channels, missing samples), then the tower's input into buffer 0 -------
+    {
+        const int words = SB * PP * (cp0 + cp1);
+        float4* z = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < words / 4; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int count = n_samples * cin0 * P;
+        const float* src = x + static_cast<size_t>(b0) * cin0 * P;
+        auto place = [&](int i, float v) {
+            const int p = i % P;
+            const int sc = i / P;
+            const int s = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin0_magic));
+            const int ci = sc - s * cin0;
+            lds[(s * PP + (p / W + 1) * PW + (p % W) + 1) * cp0 + ci] = v;
+        };
+        for (int i0 = tid * 4; i0 < count; i0 += 4 * THREADS * 4) {
+            float4 staged[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * THREADS * 4;
+                staged[k] = (i + 3 < count) ? *reinterpret_cast<const float4*>(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * THREADS * 4;
+                if (i + 3 < count) {
+                    place(i, staged[k].x), place(i + 1, staged[k].y), place(i + 2, staged[k].z), place(i + 3, staged[k].w);
+                } else {
+                    for (int q = i; q < count; ++q) place(q, src[q]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int col_tile = wave % NT;
+    const int row_group = wave / NT;
+    const int i_row = lane & 15;
+    const int kk = lane >> 4;
+    const int n_col = col_tile * 16 + i_row;
+    // plane position (word offset / channel stride) of this lane's A rows and of the D rows it stores
+    int pos_a[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int tile = row_group + t * RG;
+        int m = tile * 16 + i_row;
+        if (tile >= MT || m >= ROWS) m = 0;
+        const int sidx = m / P, p = m % P;
+        pos_a[t] = sidx * PP + (p / W + 1) * PW + (p % W) + 1;
+    }
+
+    for (int l = 0; l < args.n_layers; ++l) {
+        const TowerLayer& L = args.layer[l];
+        const float* in = buf[l & 1];
+        float* dst = buf[(l & 1) ^ 1];
+        const int CPI = cps[l & 1], CPO = cps[(l & 1) ^ 1];
+        const int cin = L.cin;
+        const int ng = conv_groups(cin);
+
+        f32x4 acc[MTW];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4* wlane = reinterpret_cast<const f32x4*>(L.wt) + kk * COUT + n_col;
+        const int last_steps = min(4, cin - (ng - 1) * kConvGroup);
+        const int iterations = 9 * ng;
+        int grp = 0, tap = 0;
+        auto lds_offset = [&]() { return ((tap / 3 - 1) * PW + (tap % 3 - 1)) * CPI + grp * kConvGroup + 4 * kk; };
+        auto advance = [&]() {
+            if (++grp == ng) {
+                grp = 0;
+                tap = tap < 8 ? tap + 1 : 8;
+            }
+        };
+        f32x4 a[MTW];
+        f32x4 b = wlane[0];
+        f32x4 b1 = wlane[4 * COUT];
+        {
+            const int off = lds_offset();
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) a[t] = *reinterpret_cast<const f32x4*>(in + pos_a[t] * CPI + off);
+            advance();
+        }
+        int grp_now = 0;
+        for (int it = 0; it < iterations; ++it) {
+            const f32x4 bn = wlane[static_cast<size_t>(it + 2) * 4 * COUT];
+            const int off = lds_offset();
+            f32x4 an[MTW];
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) an[t] = *reinterpret_cast<const f32x4*>(in + pos_a[t] * CPI + off);
+            advance();
+            const int steps = (grp_now == ng - 1) ? last_steps : 4;
+            grp_now = (grp_now + 1 == ng) ? 0 : grp_now + 1;
+            if (steps == 4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (g < steps) {
+#pragma unroll
+                        for (int t = 0; t < MTW; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) a[t] = an[t];
+            b = b1;
+            b1 = bn;
+        }
+
+        // ---- layer epilogue into the destination planes: D[row = 4 kk + r][col = lane & 15] ----------------------------
+        const float sc = L.scale[n_col], sh = L.shift[n_col];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+            const int tile = row_group + t * RG;
+            if (tile >= MT) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = tile * 16 + 4 * kk + r;
+                if (m >= ROWS) continue;
+                const int sidx = m / P, p = m % P;
+                if (sidx >= n_samples) continue;        // (missing samples stay zero)
+                float* cell = dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n_col;
+                float v = acc[t][r] * sc + sh;
+                if (L.skip) v = v + *cell;
+                if (L.relu) v = v < 0.f ? 0.f : v;
+                *cell = v;
+            }
+        }
+        __syncthreads();                                // the layer's output is complete; its input may be overwritten
+
+        if (L.export_raw || L.export_unit) {
+            const int out_count = n_samples * COUT * P;
+            const size_t g0 = static_cast<size_t>(b0) * COUT * P;
+            if (L.export_raw) {
+                for (int i = tid; i < out_count; i += THREADS) {
+                    const int p = i % P;
+                    const int sn = i / P;
+                    const int n = sn % COUT, sidx = sn / COUT;
+                    L.export_raw[g0 + i] = dst[(sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
+                }
+            }
+            if (L.export_unit) {
+                // per (sample, channel) plane: (x - min) / span, span = max - min (+ 1e-5 below 1e-5) -- models.py:525-549,
+                // the operations of unit_rescale_kernel, so the same bits
+                __syncthreads();
+                for (int q = tid; q < n_samples * COUT; q += THREADS) {
+                    const int n = q % COUT, sidx = q / COUT;
+                    float* plane = dst + (sidx * PP) * CPO + n;
+                    float lo = plane[(PW + 1) * CPO], hi = lo;
+                    for (int p = 1; p < P; ++p) {
+                        const float v = plane[((p / W + 1) * PW + (p % W) + 1) * CPO];
+                        lo = (v < lo || v != v) ? v : lo;
+                        hi = (v > hi || v != v) ? v : hi;
+                    }
+                    float span = hi - lo;
+                    if (span < 1e-5f) span = span + 1e-5f;
+                    for (int p = 0; p < P; ++p) {
+                        float* c = plane + ((p / W + 1) * PW + (p % W) + 1) * CPO;
+                        *c = (*c - lo) / span;
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < out_count; i += THREADS) {
+                    const int p = i % P;
+                    const int sn = i / P;
+                    const int n = sn % COUT, sidx = sn / COUT;
+                    L.export_unit[g0 + i] = dst[(sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NT, int H, int W, int SB>
+static int launch_board_tower(const float* x, int batch, int cin0, const TowerArgs& args, hipStream_t stream) {
+    constexpr int PP = (H + 2) * (W + 1) + 1;
+    int cp0 = conv_groups(cin0) * kConvGroup + 4;
+    int cp1 = 4;
+    for (int l = 0; l < args.n_layers; ++l) {             // layer l reads buffer l & 1
+        int& cp = (l & 1) ? cp1 : cp0;
+        cp = std::max(cp, conv_groups(args.layer[l].cin) * kConvGroup + 4);
+    }
+    cp0 = std::max(cp0, 16 * NT + 4);                     // outputs (16 NT channels) land in either buffer
+    cp1 = std::max(cp1, 16 * NT + 4);
+    const size_t lds = sizeof(float) * static_cast<size_t>(SB) * PP * (cp0 + cp1);
+    if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
+    auto kernel = board_tower_kernel<NT, H, W, SB>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds)) != hipSuccess)
+        return MZMCTS_ERR_HIP;
+    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
+    kernel<<<grid, block, lds, stream>>>(x, batch, cin0, 0xFFFFFFFFu / static_cast<uint32_t>(cin0) + 1u, cp0, cp1, args);
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
 template <int NT, int H, int W, int SB>
 static int launch_board_conv(const float* x, const float* wt, const float* scale, const float* shift, const float* residual,
                              float* out, int batch, int cin, int relu, hipStream_t stream) {
@@ -315,4 +569,31 @@ extern "C" int mzmcts_board_conv3x3(const float* x, const float* packed, const f
     }
     if (cout == 64) return mz::launch_board_conv<4, 3, 3, 16>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
     return mz::launch_board_conv<1, 3, 3, 32>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
+}
+
+extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
+                                  const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_) {
+    if (!x || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers ||
+        !mzmcts_board_conv_supported(cin0, channels, height, width))
+        return MZMCTS_ERR_INVALID;
+    mz::TowerArgs args{};
+    args.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const mzmcts_tower_layer& d = layers[l];
+        if (!d.packed || !d.scale || !d.shift || d.cin != (l == 0 ? cin0 : channels)) return MZMCTS_ERR_INVALID;
+        args.layer[l] = mz::TowerLayer{d.packed, d.scale, d.shift, d.export_raw, d.export_unit, d.cin, d.relu, d.skip, 0};
+    }
+    if (batch == 0) return MZMCTS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int b = static_cast<int>(batch);
+    if (height == 6 && width == 7) {
+        if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream);
+        return mz::launch_board_tower<1, 6, 7, 8>(x, b, cin0, args, stream);
+    }
+    if (height == 6 && width == 6) {
+        if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream);
+        return mz::launch_board_tower<1, 6, 6, 8>(x, b, cin0, args, stream);
+    }
+    if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
+    return mz::launch_board_tower<1, 3, 3, 32>(x, b, cin0, args, stream);
 }

@@ -211,6 +211,9 @@ class MuZeroFullyConnectedNetwork(AbstractNetwork):
         return value, reward, policy_logits, encoded_state
 
     def recurrent_inference(self, encoded_state, action, out_state=None):
+        if encoded_state.is_cuda and not self.training and not torch.is_grad_enabled():
+            return self.recurrent_inference_from_planes(
+                state_action_planes(encoded_state, action, self.action_space_size), out_state)
         next_state, reward = self.dynamics(encoded_state, action, out_state)
         policy_logits, value = self.prediction(next_state)
         return value, reward, policy_logits, next_state
@@ -656,6 +659,74 @@ class MuZeroResidualNetwork(AbstractNetwork):
     def prediction(self, encoded_state):
         return self.prediction_network(encoded_state)
 
+    # ---- whole towers in one launch (include/mzmcts.h mzmcts_board_tower) ----------------------------------------
+    @staticmethod
+    def _block_layers(blocks):
+        """(conv, bn, relu, skip) per layer of a list of ResidualBlocks (models.py:213-229)."""
+        layers = []
+        for block in blocks:
+            layers.append((block.conv1, block.bn1, 1, 0))
+            layers.append((block.conv2, block.bn2, 1, 1))
+        return layers
+
+    def _tower(self, x, layers, exports):
+        """Run `layers` = [(conv, bn, relu, skip)] on x in ONE launch; exports = {layer index: (raw, unit)} tensors (or
+        None) that receive that layer's output / its min-max-rescaled form.  Returns False when the tower path does
+        not apply (training, autograd, CPU, unsupported shape, activations too large for LDS): the caller then takes
+        the per-layer path."""
+        mode = os.environ.get("MZ_BOARD_CONV", "auto")
+        if (mode == "off" or os.environ.get("MZ_BOARD_TOWER", "on") == "off" or self.training or torch.is_grad_enabled()
+                or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or len(layers) > 16):
+            return False
+        lib = _native.load()
+        b, cin0, h, w = x.shape
+        channels = layers[0][0].out_channels
+        if not lib.mzmcts_board_conv_supported(cin0, channels, h, w):
+            return False
+        for conv, bn, _, _ in layers:
+            if not isinstance(conv, BoardConv2d) or conv.out_channels != channels or conv.kernel_size != (3, 3) \
+                    or conv.stride != (1, 1) or bn.training:
+                return False
+        x = x.contiguous()
+        descs = (_native.MzTowerLayer * len(layers))()
+        keep = [x]
+        for i, (conv, bn, relu, skip) in enumerate(layers):
+            scale, shift = bn.folded()
+            packed = conv.packed()
+            raw, unit = exports.get(i, (None, None))
+            keep += [scale, shift, packed, raw, unit]
+            descs[i] = _native.MzTowerLayer(packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            raw.data_ptr() if raw is not None else None,
+                                            unit.data_ptr() if unit is not None else None, conv.in_channels, relu, skip, 0)
+        with torch.cuda.device(x.device):
+            rc = lib.mzmcts_board_tower(x.data_ptr(), b, cin0, channels, h, w, ctypes.addressof(descs), len(layers),
+                                        torch.cuda.current_stream(x.device).cuda_stream)
+        if rc == -1:
+            return False                                 # (does not fit in LDS / shape not covered)
+        if rc != 0:
+            raise RuntimeError(f"mzmcts_board_tower failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+        return True
+
+    def _recurrent_tower(self, planes, out_state):
+        """dynamics + rescale + prediction towers of recurrent_inference as one launch; None if not applicable."""
+        dyn, pred = self.dynamics_network.module, self.prediction_network.module
+        layers = [(dyn.conv, dyn.bn, 1, 0)] + self._block_layers(dyn.resblocks)
+        last_dyn = len(layers) - 1
+        layers += self._block_layers(pred.resblocks)
+        b, _, h, w = planes.shape
+        c = dyn.conv.out_channels
+        raw = torch.empty((b, c, h, w), dtype=torch.float32, device=planes.device)
+        state = out_state if out_state is not None else torch.empty_like(raw)
+        if not (state.is_contiguous() and state.dtype == torch.float32 and tuple(state.shape) == (b, c, h, w)):
+            return None
+        features = torch.empty_like(raw) if len(layers) - 1 > last_dyn else None
+        exports = {last_dyn: (raw, state)}
+        if features is not None:
+            exports[len(layers) - 1] = (features, None)
+        if not self._tower(planes, layers, exports):
+            return None
+        return raw, state, features if features is not None else state
+
     def representation(self, observation):
         return board_rescale(self.representation_network(observation))
 
@@ -674,6 +745,9 @@ class MuZeroResidualNetwork(AbstractNetwork):
         return value, reward, policy_logits, encoded_state
 
     def recurrent_inference(self, encoded_state, action, out_state=None):
+        if encoded_state.is_cuda and not self.training and not torch.is_grad_enabled():
+            return self.recurrent_inference_from_planes(
+                state_action_planes(encoded_state, action, self.action_space_size), out_state)
         next_state, reward = self.dynamics(encoded_state, action, out_state)
         policy_logits, value = self.prediction(next_state)
         return value, reward, policy_logits, next_state
@@ -681,6 +755,15 @@ class MuZeroResidualNetwork(AbstractNetwork):
     def recurrent_inference_from_planes(self, planes, out_state=None):
         """recurrent_inference for a caller that already holds the dynamics input (the engine's gather writes it:
         include/mzmcts.h mzmcts_select_planes)."""
+        fused = self._recurrent_tower(planes, out_state)
+        if fused is not None:
+            raw, next_state, features = fused
+            dyn, pred = self.dynamics_network.module, self.prediction_network.module
+            reward = conv_head(raw, dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward)
+            value, policy_logits = conv_heads(features, [
+                (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value),
+                (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy)])
+            return value, reward, policy_logits, next_state
         next_state, reward = self.dynamics_from_planes(planes, out_state)
         policy_logits, value = self.prediction(next_state)
         return value, reward, policy_logits, next_state

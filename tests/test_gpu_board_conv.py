@@ -123,3 +123,37 @@ def test_residual_block_and_connect4_network_follow_the_torch_path(pkg, monkeypa
     assert not torch.allclose(after[0], fused[0])
     for a, b in zip(after, plain_after):
         torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("name,batch", [("connect4", 37), ("connect4", 1024), ("tictactoe", 130), ("atari84", 50)])
+def test_recurrent_tower_equals_the_per_layer_path(pkg, monkeypatch, name, batch):
+    """mzmcts_board_tower (dynamics + rescale + prediction towers in one launch, activations resident in LDS) against
+    the per-layer path.  Connect4's per-layer path is the same MFMA kernel per convolution and the same rescale
+    operations, so the tower must reproduce it bit for bit; the small boards' per-layer path is the dense GEMM (another
+    summation order): equal to fp32 rounding."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    from parity_helpers import synthetic_model
+    if name == "atari84":
+        config = importlib.import_module("muzero-hypermodel_amd.games.breakout").atari84_config()
+    else:
+        config = importlib.import_module(f"muzero-hypermodel_amd.games.{name}").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda")
+    g = torch.Generator().manual_seed(5)
+    engine_mod = importlib.import_module("muzero-hypermodel_amd.engine")
+    shape = engine_mod.hidden_state_shape(config)
+    state = torch.rand((batch,) + tuple(shape), generator=g).cuda()
+    action = torch.randint(0, len(config.action_space), (batch, 1), generator=g).cuda()
+    out_state = torch.full_like(state, float("nan"))
+    with torch.no_grad():
+        monkeypatch.setenv("MZ_BOARD_TOWER", "on")
+        planes = models.state_action_planes(state, action, len(config.action_space))
+        assert model._recurrent_tower(planes, None) is not None          # the tower path is really taken
+        fused = model.recurrent_inference(state, action, out_state=out_state)
+        assert fused[3].data_ptr() == out_state.data_ptr() and not torch.isnan(out_state).any()
+        monkeypatch.setenv("MZ_BOARD_TOWER", "off")
+        plain = model.recurrent_inference(state, action)
+    for a, b, what in zip(fused, plain, ("value", "reward", "policy", "state")):
+        if name == "connect4":
+            assert torch.equal(a, b), what
+        else:
+            torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5, msg=what)
