@@ -211,9 +211,6 @@ class MuZeroFullyConnectedNetwork(AbstractNetwork):
         return value, reward, policy_logits, encoded_state
 
     def recurrent_inference(self, encoded_state, action, out_state=None):
-        if encoded_state.is_cuda and not self.training and not torch.is_grad_enabled():
-            return self.recurrent_inference_from_planes(
-                state_action_planes(encoded_state, action, self.action_space_size), out_state)
         next_state, reward = self.dynamics(encoded_state, action, out_state)
         policy_logits, value = self.prediction(next_state)
         return value, reward, policy_logits, next_state
