@@ -361,12 +361,26 @@ int mzmcts_board_conv3x3(const float *x, const float *packed, const float *scale
  * (models.py:399-420, 500-522, 586-602).  n_layers <= 16; shapes as mzmcts_board_conv_supported; MZMCTS_ERR_INVALID
  * when two activation buffers of the workgroup do not fit in LDS (the caller keeps the per-layer path). */
 typedef struct mzmcts_tower_layer {
-    const float *packed, *scale, *shift;
+    const void *packed;        /* mzmcts_board_conv_pack (fp32 tower) or mzmcts_board_conv_pack_split (split tower) */
+    const float *scale, *shift;
+    const float *const_table;  /* split tower, layer 0 with a constant last input plane: its table; else NULL */
     float *export_raw, *export_unit;
     int32_t cin, relu, skip, reserved;
 } mzmcts_tower_layer;
 int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
                        const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
+/* The same tower (channels == 64) on the 16-bit matrix path at fp32 accuracy: every operand is carried as two fp16
+ * halves (22 significant bits), a product as three fp16 MFMAs with fp32 accumulation -- representation error below an
+ * fp32 fmaf chain's rounding, 5.3 x fewer matrix-pipe cycles (csrc/board_conv.hip).  Weights come from
+ * mzmcts_board_conv_pack_split (mzmcts_board_conv_split_halfs(cin_conv, cout) 16-bit words; cin_conv = cin - 1 when
+ * const_plane).  const_plane != 0: the LAST input plane of x is one constant per sample (the dynamics input's action
+ * plane, models.py:553-568); it is not convolved, its contribution comes from `const_table` (dev f32[cout, height *
+ * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN). */
+int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout);
+int mzmcts_board_conv_pack_split(const float *weight, void *packed, float *const_table, int32_t cin, int32_t cout,
+                                 int32_t const_plane, int32_t height, int32_t width, void *stream);
+int mzmcts_board_tower_split(const float *x, int64_t batch, int32_t cin0, int32_t const_plane, int32_t channels,
+                             int32_t height, int32_t width, const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);

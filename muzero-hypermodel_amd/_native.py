@@ -111,6 +111,9 @@ PROTOTYPES = {
     "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
     "mzmcts_board_conv3x3": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void]),
     "mzmcts_board_tower": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 + [c_void, ctypes.c_int32, c_void]),
+    "mzmcts_board_conv_split_halfs": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
+    "mzmcts_board_conv_pack_split": (ctypes.c_int, [c_void, c_void, c_void] + [ctypes.c_int32] * 5 + [c_void]),
+    "mzmcts_board_tower_split": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
     "mzenv_advance": (ctypes.c_int, [c_void] * 10),
@@ -288,7 +291,8 @@ class HostRng:
 class MzTowerLayer(ctypes.Structure):
     """include/mzmcts.h mzmcts_tower_layer"""
     _fields_ = [("packed", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
-                ("export_raw", ctypes.c_void_p), ("export_unit", ctypes.c_void_p), ("cin", ctypes.c_int32),
+                ("const_table", ctypes.c_void_p), ("export_raw", ctypes.c_void_p), ("export_unit", ctypes.c_void_p),
+                ("cin", ctypes.c_int32),
                 ("relu", ctypes.c_int32), ("skip", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 

@@ -501,6 +501,337 @@ static int launch_board_tower(const float* x, int batch, int cin0, const TowerAr
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// The same tower on the 16-bit matrix path at fp32 accuracy ("split" precision): every fp32 operand is carried as TWO
+// fp16 numbers, x * 2^s = h0 + h1 (h0 = fp16(x 2^s), h1 = fp16(x 2^s - h0): 22 significant bits), and a product as
+//     a b  ~  (a0 b0) + (a0 b1 + a1 b0)          (three v_mfma_f32_16x16x32_f16, fp32 accumulation; a1 b1 ~ 2^-22 dropped)
+// with the three partial sums kept in two accumulators (large / small terms).  The representation error of a length-576
+// dot product is below that of an fp32 fmaf chain (measured: rms 0.7e-8 vs 3.3e-8 of sum |a b|), at 3 x 16 cycles per 32
+// input channels instead of 8 x 32: 5.3 x fewer matrix-pipe cycles than the fp32 form, which on this chip runs into
+// its power limit (the fp32 tower sustains ~1.1 GHz-equivalent).  Powers of two (activations x 8, weights x 64) keep
+// the low halves out of the fp16 subnormal range; they are removed exactly in the epilogue.  |activation| must stay
+// below 8188 (fp16 range / 8): larger values become inf / NaN, never a silently wrong number.
+// Activations live in LDS as [position][2 halves][channel] fp16; the skip connection and the exports read h0 + h1.
+// The dynamics input's action plane (one constant per sample, models.py:553-568) is not convolved: its contribution
+// a * sum over the taps inside the board of w[n][C][tap] comes from a table made at pack time (fp32).
+// -------------------------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float kActScale = 8.f, kWtScale = 64.f;
+constexpr int kSplitGroup = 32;   // input channels per MFMA (K of v_mfma_f32_16x16x32_f16)
+
+__host__ __device__ inline int split_groups(int cin) { return (cin + kSplitGroup - 1) / kSplitGroup; }
+__host__ __device__ inline int64_t split_packed_halfs(int cin, int cout) {   // [9 NG + 2 spare][2 q][4 kk][cout][8 j]
+    return static_cast<int64_t>(9 * split_groups(cin) + 2) * 2 * 4 * cout * 8;
+}
+
+// wh[((((tap * NG + grp) * 2 + q) * 4 + kk) * cout + n) * 8 + j] = half q of 64 * w[n][grp * 32 + 8 kk + j][tap]
+// over the first `cin_conv` input channels of a [cout, cin_total, 3, 3] weight (0 beyond, and in the spare groups).
+__global__ __launch_bounds__(256) void board_conv_pack_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wh,
+                                                                    int cin_total, int cin_conv, int cout) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= split_packed_halfs(cin_conv, cout)) return;
+    const int j = static_cast<int>(i & 7);
+    const int n = static_cast<int>((i >> 3) % cout);
+    const int kk = static_cast<int>(((i >> 3) / cout) & 3);
+    const int q = static_cast<int>(((i >> 3) / cout / 4) & 1);
+    const int tg = static_cast<int>((i >> 3) / cout / 8);
+    const int ng = split_groups(cin_conv);
+    const int tap = tg / ng, grp = tg % ng;
+    const int ci = grp * kSplitGroup + 8 * kk + j;
+    float v = (tap < 9 && ci < cin_conv) ? w[(static_cast<size_t>(n) * cin_total + ci) * 9 + tap] * kWtScale : 0.f;
+    const _Float16 h0 = static_cast<_Float16>(v);
+    const _Float16 h1 = static_cast<_Float16>(v - static_cast<float>(h0));
+    wh[i] = q ? h1 : h0;
+}
+
+// table[n * P + p] = sum over the taps whose source position lies inside the H x W board of w[n][ci][tap]
+__global__ __launch_bounds__(256) void board_conv_const_plane_kernel(const float* __restrict__ w, float* __restrict__ table,
+                                                                     int cin_total, int ci, int cout, int H, int W) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cout * H * W) return;
+    const int p = i % (H * W), n = i / (H * W);
+    const int y = p / W, xx = p % W;
+    float acc = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+        if (yy >= 0 && yy < H && xs >= 0 && xs < W) acc += w[(static_cast<size_t>(n) * cin_total + ci) * 9 + tap];
+    }
+    table[i] = acc;
+}
+
+struct SplitLayer {
+    const _Float16* wh;        // packed split weights
+    const float* scale;
+    const float* shift;
+    const float* const_table;  // layer 0 only: the constant plane's contribution per (channel, position), or null
+    float* export_raw;
+    float* export_unit;
+    int32_t cin;               // channels convolved (without the constant plane)
+    int32_t relu, skip, pad;
+};
+struct SplitArgs {
+    SplitLayer layer[kMaxTowerLayers];
+    int32_t n_layers;
+};
+
+template <int H, int W, int SB>
+__global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(const float* __restrict__ x, int batch, int cin0,
+                                                                             int const_plane, uint32_t cin_load_magic,
+                                                                             int cph0, int cph1, SplitArgs args) {
+    constexpr int P = H * W;
+    constexpr int PW = W + 1;
+    constexpr int PP = (H + 2) * PW + 1;
+    constexpr int ROWS = SB * P;
+    constexpr int MT = (ROWS + 15) / 16;
+    constexpr int RG = 4;                               // row groups; wave = (column pair, row group)
+    constexpr int MTW = (MT + RG - 1) / RG;
+    constexpr int COUT = 64;
+    constexpr int THREADS = 64 * kConvWaves;
+    extern __shared__ __attribute__((aligned(16))) _Float16 hl[];   // buffer 0 [SB*PP][2][cph0] | buffer 1 [SB*PP][2][cph1] | consts
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b0 = blockIdx.x * SB;
+    const int n_samples = min(SB, batch - b0);
+    _Float16* const buf[2] = {hl, hl + SB * PP * 2 * cph0};
+    const int cphs[2] = {cph0, cph1};
+    float* aconst = reinterpret_cast<float*>(hl + SB * PP * 2 * (cph0 + cph1));   // [SB] the constant plane's value
+
+    auto plane_pos = [&](int p) { return (p / W + 1) * PW + (p % W) + 1; };
+    auto store_val = [&](_Float16* b, int cph, int pos, int n, float v) {
+        const float vs = v * kActScale;
+        const _Float16 h0 = static_cast<_Float16>(vs);
+        const _Float16 h1 = static_cast<_Float16>(vs - static_cast<float>(h0));
+        b[pos * 2 * cph + n] = h0;
+        b[pos * 2 * cph + cph + n] = h1;
+    };
+    auto load_val = [&](const _Float16* b, int cph, int pos, int n) {
+        return (static_cast<float>(b[pos * 2 * cph + n]) + static_cast<float>(b[pos * 2 * cph + cph + n])) * (1.0f / kActScale);
+    };
+
+    // ---- zero both buffers, then the tower's input (without the constant plane) into buffer 0 ---------------------
+    {
+        const int bytes = (SB * PP * 2 * (cph0 + cph1)) * 2;          // a multiple of 16
+        float4* z = reinterpret_cast<float4*>(hl);
+        for (int i = tid; i < bytes / 16; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    {
+        const int cin_load = cin0 - const_plane;
+        const float* src = x + static_cast<size_t>(b0) * cin0 * P;
+        if (tid < SB) aconst[tid] = (const_plane && tid < n_samples) ? src[(static_cast<size_t>(tid) * cin0 + cin_load) * P] : 0.f;
+        const int count = n_samples * cin_load * P;       // elements to place; sample s, channel ci, position p
+        for (int i0 = tid; i0 < count; i0 += 4 * THREADS) {
+            float v[4];
+            int at[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * THREADS;
+                at[k] = -1;
+                v[k] = 0.f;
+                if (i < count) {
+                    const int p = i % P;
+                    const int sc = i / P;                 // s * cin_load + ci
+                    const int sidx = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin_load_magic));
+                    const int ci = sc - sidx * cin_load;
+                    v[k] = src[(static_cast<size_t>(sidx) * cin0 + ci) * P + p];
+                    at[k] = (sidx * PP + plane_pos(p)) * 2 * cph0 + ci;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (at[k] >= 0) {
+                    const float vs = v[k] * kActScale;
+                    const _Float16 h0 = static_cast<_Float16>(vs);
+                    hl[at[k]] = h0;
+                    hl[at[k] + cph0] = static_cast<_Float16>(vs - static_cast<float>(h0));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int col_pair = wave & 1;                      // output channels col_pair * 32 .. + 31
+    const int row_group = wave >> 1;
+    const int i_row = lane & 15;
+    const int kk = lane >> 4;
+    int pos_a[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int tile = row_group + t * RG;
+        int m = tile * 16 + i_row;
+        if (tile >= MT || m >= ROWS) m = 0;
+        pos_a[t] = (m / P) * PP + plane_pos(m % P);
+    }
+
+    for (int l = 0; l < args.n_layers; ++l) {
+        const SplitLayer& L = args.layer[l];
+        const _Float16* in = buf[l & 1];
+        _Float16* dst = buf[(l & 1) ^ 1];
+        const int CPI = cphs[l & 1], CPO = cphs[(l & 1) ^ 1];
+        const int ng = split_groups(L.cin);
+        const int iterations = 9 * ng;
+
+        f32x4 hi[MTW][2], lo[MTW][2];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) hi[t][c] = lo[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // lane (column n, kk) of column tile c reads half q of its 8 channels at wlane[(q * 4) * COUT * ... ] (16 bytes)
+        const h8* wlane = reinterpret_cast<const h8*>(L.wh) + kk * COUT + col_pair * 32 + i_row;
+        auto wload = [&](int it, int c, int q) { return wlane[(static_cast<size_t>(it) * 2 + q) * 4 * COUT + 16 * c]; };
+        int grp = 0, tap = 0;
+        auto lds_offset = [&]() { return ((tap / 3 - 1) * PW + (tap % 3 - 1)) * 2 * CPI + grp * kSplitGroup + 8 * kk; };
+        auto advance = [&]() {
+            if (++grp == ng) {
+                grp = 0;
+                tap = tap < 8 ? tap + 1 : 8;
+            }
+        };
+        h8 a[MTW][2], b[2][2], b1[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                b[c][q] = wload(0, c, q);
+                b1[c][q] = wload(1, c, q);
+            }
+        {
+            const int off = lds_offset();
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a[t][q] = *reinterpret_cast<const h8*>(in + pos_a[t] * 2 * CPI + q * CPI + off);
+            advance();
+        }
+        for (int it = 0; it < iterations; ++it) {
+            h8 bn[2][2], an[MTW][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bn[c][q] = wload(it + 2, c, q);   // (two spare zero groups follow the last)
+            const int off = lds_offset();
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) an[t][q] = *reinterpret_cast<const h8*>(in + pos_a[t] * 2 * CPI + q * CPI + off);
+            advance();
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) hi[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], b[c][0], hi[t][c], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], b[c][1], lo[t][c], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], b[c][0], lo[t][c], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) a[t][q] = an[t][q];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    b[c][q] = b1[c][q];
+                    b1[c][q] = bn[c][q];
+                }
+        }
+
+        // ---- layer epilogue: D[row = 4 kk + r][col = lane & 15] of column tiles 2 col_pair, 2 col_pair + 1 --------------
+        constexpr float kDescale = 1.0f / (kActScale * kWtScale);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = col_pair * 32 + c * 16 + i_row;
+            const float sc = L.scale[n], sh = L.shift[n];
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+                const int tile = row_group + t * RG;
+                if (tile >= MT) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = tile * 16 + 4 * kk + r;
+                    if (m >= ROWS) continue;
+                    const int sidx = m / P, p = m % P;
+                    if (sidx >= n_samples) continue;
+                    const int pos = sidx * PP + plane_pos(p);
+                    float conv = (hi[t][c][r] + lo[t][c][r]) * kDescale;
+                    if (L.const_table) conv = conv + aconst[sidx] * L.const_table[n * P + p];
+                    float v = conv * sc + sh;
+                    if (L.skip) v = v + load_val(dst, CPO, pos, n);
+                    if (L.relu) v = v < 0.f ? 0.f : v;
+                    store_val(dst, CPO, pos, n, v);
+                }
+            }
+        }
+        __syncthreads();
+
+        if (L.export_raw || L.export_unit) {
+            const int out_count = n_samples * COUT * P;
+            const size_t g0 = static_cast<size_t>(b0) * COUT * P;
+            if (L.export_raw) {
+                for (int i = tid; i < out_count; i += THREADS) {
+                    const int p = i % P;
+                    const int sn = i / P;
+                    L.export_raw[g0 + i] = load_val(dst, CPO, (sn / COUT) * PP + plane_pos(p), sn % COUT);
+                }
+            }
+            if (L.export_unit) {
+                __syncthreads();
+                for (int q = tid; q < n_samples * COUT; q += THREADS) {   // per plane: models.py:525-549
+                    const int n = q % COUT, sidx = q / COUT;
+                    float lo_v = load_val(dst, CPO, sidx * PP + plane_pos(0), n), hi_v = lo_v;
+                    for (int p = 1; p < P; ++p) {
+                        const float v = load_val(dst, CPO, sidx * PP + plane_pos(p), n);
+                        lo_v = (v < lo_v || v != v) ? v : lo_v;
+                        hi_v = (v > hi_v || v != v) ? v : hi_v;
+                    }
+                    float span = hi_v - lo_v;
+                    if (span < 1e-5f) span = span + 1e-5f;
+                    for (int p = 0; p < P; ++p) {
+                        const int pos = sidx * PP + plane_pos(p);
+                        store_val(dst, CPO, pos, n, (load_val(dst, CPO, pos, n) - lo_v) / span);
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < out_count; i += THREADS) {
+                    const int p = i % P;
+                    const int sn = i / P;
+                    L.export_unit[g0 + i] = load_val(dst, CPO, (sn / COUT) * PP + plane_pos(p), sn % COUT);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int H, int W, int SB>
+static int launch_board_tower_split(const float* x, int batch, int cin0, int const_plane, const SplitArgs& args,
+                                    hipStream_t stream) {
+    constexpr int PP = (H + 2) * (W + 1) + 1;
+    int cph0 = 64 + 8, cph1 = 64 + 8;                     // outputs are 64 channels in either buffer
+    for (int l = 0; l < args.n_layers; ++l) {
+        int& cp = (l & 1) ? cph1 : cph0;
+        cp = std::max(cp, split_groups(args.layer[l].cin) * kSplitGroup + 8);
+    }
+    const size_t lds = sizeof(_Float16) * static_cast<size_t>(SB) * PP * 2 * (cph0 + cph1) + sizeof(float) * SB;
+    if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
+    auto kernel = board_tower_split_kernel<H, W, SB>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds)) != hipSuccess)
+        return MZMCTS_ERR_HIP;
+    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
+    const int cin_load = cin0 - const_plane;
+    kernel<<<grid, block, lds, stream>>>(x, batch, cin0, const_plane, 0xFFFFFFFFu / static_cast<uint32_t>(cin_load) + 1u, cph0,
+                                         cph1, args);
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
 template <int NT, int H, int W, int SB>
 static int launch_board_conv(const float* x, const float* wt, const float* scale, const float* shift, const float* residual,
                              float* out, int batch, int cin, int relu, hipStream_t stream) {
@@ -581,7 +912,7 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     for (int l = 0; l < n_layers; ++l) {
         const mzmcts_tower_layer& d = layers[l];
         if (!d.packed || !d.scale || !d.shift || d.cin != (l == 0 ? cin0 : channels)) return MZMCTS_ERR_INVALID;
-        args.layer[l] = mz::TowerLayer{d.packed, d.scale, d.shift, d.export_raw, d.export_unit, d.cin, d.relu, d.skip, 0};
+        args.layer[l] = mz::TowerLayer{static_cast<const float*>(d.packed), d.scale, d.shift, d.export_raw, d.export_unit, d.cin, d.relu, d.skip, 0};
     }
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -596,4 +927,50 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
     return mz::launch_board_tower<1, 3, 3, 32>(x, b, cin0, args, stream);
+}
+
+extern "C" int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout) {
+    if (cin_conv <= 0 || cout <= 0) return -1;
+    return mz::split_packed_halfs(cin_conv, cout);
+}
+
+extern "C" int mzmcts_board_conv_pack_split(const float* weight, void* packed, float* const_table, int32_t cin, int32_t cout,
+                                            int32_t const_plane, int32_t height, int32_t width, void* stream_) {
+    if (!weight || !packed || cin <= 0 || cout <= 0 || (const_plane && (!const_table || cin < 2 || height <= 0 || width <= 0)))
+        return MZMCTS_ERR_INVALID;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int cin_conv = cin - (const_plane ? 1 : 0);
+    const int64_t total = mz::split_packed_halfs(cin_conv, cout);
+    mz::board_conv_pack_split_kernel<<<dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, stream>>>(
+        weight, static_cast<_Float16*>(packed), cin, cin_conv, cout);
+    if (const_plane)
+        mz::board_conv_const_plane_kernel<<<dim3((cout * height * width + 255) / 256), dim3(256), 0, stream>>>(
+            weight, const_table, cin, cin - 1, cout, height, width);
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+extern "C" int mzmcts_board_tower_split(const float* x, int64_t batch, int32_t cin0, int32_t const_plane, int32_t channels,
+                                        int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers,
+                                        void* stream_) {
+    if (!x || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers || channels != 64 ||
+        !mzmcts_board_conv_supported(cin0, channels, height, width) || (const_plane && cin0 < 2))
+        return MZMCTS_ERR_INVALID;
+    mz::SplitArgs args{};
+    args.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const mzmcts_tower_layer& d = layers[l];
+        const int cin_conv = l == 0 ? cin0 - (const_plane ? 1 : 0) : channels;
+        if (!d.packed || !d.scale || !d.shift || d.cin != (l == 0 ? cin0 : channels) ||
+            (l == 0 && const_plane && !d.const_table))
+            return MZMCTS_ERR_INVALID;
+        args.layer[l] = mz::SplitLayer{static_cast<const _Float16*>(d.packed), d.scale, d.shift,
+                                       (l == 0 && const_plane) ? d.const_table : nullptr, d.export_raw, d.export_unit,
+                                       cin_conv, d.relu, d.skip, 0};
+    }
+    if (batch == 0) return MZMCTS_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int b = static_cast<int>(batch);
+    if (height == 6 && width == 7) return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream);
+    if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream);
+    return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream);
 }

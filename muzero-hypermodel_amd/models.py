@@ -383,6 +383,34 @@ class BoardConv2d(torch.nn.Conv2d):
             raise RuntimeError(f"mzmcts_board_conv_pack failed ({rc})")
         self._packed_version = self._dense_key()
 
+    def packed_split(self, const_plane, h, w):
+        """(weights as two fp16 halves in the split tower's layout, table of the constant last input plane or None);
+        same buffers for the module's lifetime, refilled when the weight changes or on refold()."""
+        lib = _native.load()
+        cache = self.__dict__.setdefault("_packed_split", {})
+        key = (bool(const_plane), h, w, str(self.weight.device))
+        if key not in cache:
+            n = lib.mzmcts_board_conv_split_halfs(self.in_channels - (1 if const_plane else 0), self.out_channels)
+            cache[key] = [torch.empty(n, dtype=torch.float16, device=self.weight.device),
+                          torch.empty(self.out_channels * h * w, dtype=torch.float32, device=self.weight.device)
+                          if const_plane else None, None]
+        entry = cache[key]
+        if entry[2] != self._dense_key():
+            self._repack_split(key)
+        return entry[0], entry[1]
+
+    def _repack_split(self, key):
+        const_plane, h, w, _ = key
+        halves, table, _ = self.__dict__["_packed_split"][key]
+        with torch.cuda.device(halves.device):
+            rc = _native.load().mzmcts_board_conv_pack_split(
+                self.weight.data_ptr(), halves.data_ptr(), table.data_ptr() if table is not None else None,
+                self.in_channels, self.out_channels, 1 if const_plane else 0, h, w,
+                torch.cuda.current_stream(halves.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mzmcts_board_conv_pack_split failed ({rc})")
+        self.__dict__["_packed_split"][key][2] = self._dense_key()
+
     def fused(self, x, bn, residual=None, relu=True):
         """relu(bn(conv(x)) [+ residual]) in one launch on the matrix cores."""
         scale, shift = bn.folded()
@@ -429,6 +457,8 @@ class BoardConv2d(torch.nn.Conv2d):
         them), in place."""
         if self.__dict__.get("_packed") is not None:
             self._repack()
+        for key in self.__dict__.get("_packed_split", {}):
+            self._repack_split(key)
         with torch.no_grad():
             for (h, w, _), matrix in self.__dict__.get("_dense", {}).items():
                 index, mask = self._expansion(h, w, self.weight.device)
@@ -666,7 +696,7 @@ class MuZeroResidualNetwork(AbstractNetwork):
             layers.append((block.conv2, block.bn2, 1, 1))
         return layers
 
-    def _tower(self, x, layers, exports):
+    def _tower(self, x, layers, exports, const_plane=False):
         """Run `layers` = [(conv, bn, relu, skip)] on x in ONE launch; exports = {layer index: (raw, unit)} tensors (or
         None) that receive that layer's output / its min-max-rescaled form.  Returns False when the tower path does
         not apply (training, autograd, CPU, unsupported shape, activations too large for LDS): the caller then takes
@@ -685,19 +715,32 @@ class MuZeroResidualNetwork(AbstractNetwork):
                     or conv.stride != (1, 1) or bn.training:
                 return False
         x = x.contiguous()
+        # 64-channel towers run on the 16-bit matrix path with every operand split into two fp16 halves (fp32-level
+        # accuracy, csrc/board_conv.hip); MZ_BOARD_CONV_PRECISION=fp32 keeps the exact-fp32 MFMA form
+        split = channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
         descs = (_native.MzTowerLayer * len(layers))()
         keep = [x]
         for i, (conv, bn, relu, skip) in enumerate(layers):
             scale, shift = bn.folded()
-            packed = conv.packed()
+            table = None
+            if split:
+                packed, table = conv.packed_split(const_plane and i == 0, h, w)
+            else:
+                packed = conv.packed()
             raw, unit = exports.get(i, (None, None))
-            keep += [scale, shift, packed, raw, unit]
+            keep += [scale, shift, packed, table, raw, unit]
             descs[i] = _native.MzTowerLayer(packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            table.data_ptr() if table is not None else None,
                                             raw.data_ptr() if raw is not None else None,
                                             unit.data_ptr() if unit is not None else None, conv.in_channels, relu, skip, 0)
         with torch.cuda.device(x.device):
-            rc = lib.mzmcts_board_tower(x.data_ptr(), b, cin0, channels, h, w, ctypes.addressof(descs), len(layers),
-                                        torch.cuda.current_stream(x.device).cuda_stream)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if split:
+                rc = lib.mzmcts_board_tower_split(x.data_ptr(), b, cin0, 1 if const_plane else 0, channels, h, w,
+                                                  ctypes.addressof(descs), len(layers), stream)
+            else:
+                rc = lib.mzmcts_board_tower(x.data_ptr(), b, cin0, channels, h, w, ctypes.addressof(descs), len(layers),
+                                            stream)
         if rc == -1:
             return False                                 # (does not fit in LDS / shape not covered)
         if rc != 0:
@@ -720,7 +763,7 @@ class MuZeroResidualNetwork(AbstractNetwork):
         exports = {last_dyn: (raw, state)}
         if features is not None:
             exports[len(layers) - 1] = (features, None)
-        if not self._tower(planes, layers, exports):
+        if not self._tower(planes, layers, exports, const_plane=True):   # (the last input plane is action / A)
             return None
         return raw, state, features if features is not None else state
 

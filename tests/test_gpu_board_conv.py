@@ -125,8 +125,9 @@ def test_residual_block_and_connect4_network_follow_the_torch_path(pkg, monkeypa
         torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5)
 
 
-@pytest.mark.parametrize("name,batch", [("connect4", 37), ("connect4", 1024), ("tictactoe", 130), ("atari84", 50)])
-def test_recurrent_tower_equals_the_per_layer_path(pkg, monkeypatch, name, batch):
+@pytest.mark.parametrize("name,batch,precision", [("connect4", 37, "fp32"), ("connect4", 1024, "fp32"), ("connect4", 37, "split"),
+                                                  ("connect4", 1024, "split"), ("tictactoe", 130, "fp32"), ("atari84", 50, "fp32")])
+def test_recurrent_tower_equals_the_per_layer_path(pkg, monkeypatch, name, batch, precision):
     """mzmcts_board_tower (dynamics + rescale + prediction towers in one launch, activations resident in LDS) against
     the per-layer path.  Connect4's per-layer path is the same MFMA kernel per convolution and the same rescale
     operations, so the tower must reproduce it bit for bit; the small boards' per-layer path is the dense GEMM (another
@@ -144,6 +145,7 @@ def test_recurrent_tower_equals_the_per_layer_path(pkg, monkeypatch, name, batch
     state = torch.rand((batch,) + tuple(shape), generator=g).cuda()
     action = torch.randint(0, len(config.action_space), (batch, 1), generator=g).cuda()
     out_state = torch.full_like(state, float("nan"))
+    monkeypatch.setenv("MZ_BOARD_CONV_PRECISION", precision)
     with torch.no_grad():
         monkeypatch.setenv("MZ_BOARD_TOWER", "on")
         planes = models.state_action_planes(state, action, len(config.action_space))
@@ -153,7 +155,44 @@ def test_recurrent_tower_equals_the_per_layer_path(pkg, monkeypatch, name, batch
         monkeypatch.setenv("MZ_BOARD_TOWER", "off")
         plain = model.recurrent_inference(state, action)
     for a, b, what in zip(fused, plain, ("value", "reward", "policy", "state")):
-        if name == "connect4":
+        if name == "connect4" and precision == "fp32":
             assert torch.equal(a, b), what
+        elif precision == "split":
+            # two-half fp16 operands, three products: fp32-level accuracy (the logits of 13 stacked convolutions agree
+            # with the exact-fp32 chain to a few 1e-6; the rescaled state amplifies small spans)
+            print(what, float((a - b).abs().max()))
+            tol = 1e-4 if what == "state" else 5e-6       # (a plane's min-max rescale divides by its span)
+            torch.testing.assert_close(a, b, rtol=tol, atol=tol, msg=what)
         else:
             torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-5, msg=what)
+
+
+def test_split_tower_single_layer_against_fp64(lib):
+    """One 64 -> 64 layer through mzmcts_board_tower_split on random data, and a 65 -> 64 layer whose last input plane
+    is constant per sample (the dynamics input): error against an fp64 convolution below an fp32 fmaf chain's."""
+    native = importlib.import_module("muzero-hypermodel_amd._native")
+    g = torch.Generator().manual_seed(11)
+    for cin, const_plane in ((64, 0), (65, 1)):
+        b, cout, h, w = 203, 64, 6, 7
+        x = torch.randn((b, cin, h, w), generator=g).cuda()
+        if const_plane:
+            x[:, -1] = torch.rand((b, 1, 1), generator=g).cuda()
+        weight = (torch.randn((cout, cin, 3, 3), generator=g) / (9 * cin) ** 0.5).cuda()
+        halves = torch.empty(lib.mzmcts_board_conv_split_halfs(cin - const_plane, cout), dtype=torch.float16, device="cuda")
+        table = torch.empty(cout * h * w, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        assert lib.mzmcts_board_conv_pack_split(weight.data_ptr(), halves.data_ptr(), table.data_ptr(), cin, cout, const_plane,
+                                                h, w, stream) == 0
+        one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+        out = torch.full((b, cout, h, w), float("nan"), device="cuda")
+        layer = (native.MzTowerLayer * 1)(native.MzTowerLayer(halves.data_ptr(), one.data_ptr(), zero.data_ptr(),
+                                                              table.data_ptr() if const_plane else None, out.data_ptr(), None,
+                                                              cin, 0, 0, 0))
+        import ctypes
+        assert lib.mzmcts_board_tower_split(x.data_ptr(), b, cin, const_plane, cout, h, w, ctypes.addressof(layer), 1, stream) == 0
+        torch.cuda.synchronize()
+        want = torch.nn.functional.conv2d(x.double().cpu(), weight.double().cpu(), padding=1)
+        magnitude = torch.nn.functional.conv2d(x.abs().double().cpu(), weight.abs().double().cpu(), padding=1)
+        err = float(((out.double().cpu() - want).abs() / magnitude).max())
+        print(f"split tower layer {cin}->{cout}: max error / sum|a b| = {err:.2e}")
+        assert err < 4e-7

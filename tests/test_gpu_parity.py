@@ -313,9 +313,10 @@ def native_vs_fixture(eng, model, config, fx, idx, expected_divergent=(), value_
 RESNET_TOL = dict(value_tol=1.5e-4, logit_tol=1e-5)
 # traces whose search leaves the reference's path on MI355X because an fp32-rounding-sized difference of the
 # network outputs flips a UCB near-tie (trace index: see the report); everything else must match move for move
-# connect4: traces 9, 21 and 23 leave the reference's path at simulation 138 / 146 / 167 of 200 (27/30 identical; 21 and
-# 23 flip with MIOpen's convolution as well as with the HIP one, 9 with the HIP one only)
-EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (9, 21, 23), "atari84": ()}
+# connect4 (default path: the split-precision tower kernel): traces 23 and 29 leave the reference's path at simulation
+# 167 / 183 of 200, 28/30 identical.  Which near-ties flip depends on the fp32 rounding of the network path: MIOpen's
+# convolution flips 21 and 23, the exact-fp32 MFMA kernel 9, 21 and 23 (MZ_BOARD_CONV_PRECISION=fp32).
+EXPECTED_DIVERGENT = {"cartpole": (), "tictactoe": (), "connect4": (23, 29), "atari84": ()}
 
 
 def test_native_cartpole_vs_reference(eng, models_mod):
@@ -497,8 +498,8 @@ def test_mcts_run_override_root_with(eng, models_mod, pkg):
             assert list(given.children) == legal and given.to_play == to_play and given.visit_count == plain.visit_count
             for a in legal:
                 assert given.children[a].visit_count == plain.children[a].visit_count
-                # (the hand-built root's priors are torch's CPU softmax, the engine's its own fp32 softmax: one ulp apart)
-                assert given.children[a].prior == pytest.approx(plain.children[a].prior, abs=2e-8)
+                # (the hand-built root's priors are torch's CPU softmax, the engine's its own fp32 softmax: a couple of ulps apart)
+                assert given.children[a].prior == pytest.approx(plain.children[a].prior, abs=2e-7)
                 assert given.children[a].value_sum == pytest.approx(plain.children[a].value_sum, rel=1e-6, abs=1e-6)
             if noise:                                      # the recorded reference search, when paths agree
                 assert [given.children[a].visit_count for a in legal] == fx["visits"][i][: len(legal)].tolist()
