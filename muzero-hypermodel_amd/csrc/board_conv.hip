@@ -295,8 +295,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int wave = tid >> 6;
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
-    float* const buf[2] = {lds, lds + SB * PP * cp0};
-    const int cps[2] = {cp0, cp1};
+    const int buf1_at = SB * PP * cp0;                  // (offsets into lds, so that every access stays an LDS access)
 
     // ---- zero both buffers (borders, padding channels, missing samples), then the tower's input into buffer 0 -------
     {
@@ -353,9 +352,9 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
 
     for (int l = 0; l < args.n_layers; ++l) {
         const TowerLayer& L = args.layer[l];
-        const float* in = buf[l & 1];
-        float* dst = buf[(l & 1) ^ 1];
-        const int CPI = cps[l & 1], CPO = cps[(l & 1) ^ 1];
+        const int in = (l & 1) ? buf1_at : 0;
+        const int dst = (l & 1) ? 0 : buf1_at;
+        const int CPI = (l & 1) ? cp1 : cp0, CPO = (l & 1) ? cp0 : cp1;
         const int cin = L.cin;
         const int ng = conv_groups(cin);
 
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         {
             const int off = lds_offset();
 #pragma unroll
-            for (int t = 0; t < MTW; ++t) a[t] = *reinterpret_cast<const f32x4*>(in + pos_a[t] * CPI + off);
+            for (int t = 0; t < MTW; ++t) a[t] = reinterpret_cast<const f32x4*>(lds)[(in + pos_a[t] * CPI + off) >> 2];   // (16-byte aligned)
             advance();
         }
         int grp_now = 0;
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
             const int off = lds_offset();
             f32x4 an[MTW];
 #pragma unroll
-            for (int t = 0; t < MTW; ++t) an[t] = *reinterpret_cast<const f32x4*>(in + pos_a[t] * CPI + off);
+            for (int t = 0; t < MTW; ++t) an[t] = reinterpret_cast<const f32x4*>(lds)[(in + pos_a[t] * CPI + off) >> 2];
             advance();
             const int steps = (grp_now == ng - 1) ? last_steps : 4;
             grp_now = (grp_now + 1 == ng) ? 0 : grp_now + 1;
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                 if (m >= ROWS) continue;
                 const int sidx = m / P, p = m % P;
                 if (sidx >= n_samples) continue;        // (missing samples stay zero)
-                float* cell = dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n_col;
+                float* cell = &lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n_col];
                 float v = acc[t][r] * sc + sh;
                 if (L.skip) v = v + *cell;
                 if (L.relu) v = v < 0.f ? 0.f : v;
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                     const int p = i % P;
                     const int sn = i / P;
                     const int n = sn % COUT, sidx = sn / COUT;
-                    L.export_raw[g0 + i] = dst[(sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
+                    L.export_raw[g0 + i] = lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
                 }
             }
             if (L.export_unit) {
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                 __syncthreads();
                 for (int q = tid; q < n_samples * COUT; q += THREADS) {
                     const int n = q % COUT, sidx = q / COUT;
-                    float* plane = dst + (sidx * PP) * CPO + n;
+                    float* plane = &lds[dst + (sidx * PP) * CPO + n];
                     float lo = plane[(PW + 1) * CPO], hi = lo;
                     for (int p = 1; p < P; ++p) {
                         const float v = plane[((p / W + 1) * PW + (p % W) + 1) * CPO];
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                     const int p = i % P;
                     const int sn = i / P;
                     const int n = sn % COUT, sidx = sn / COUT;
-                    L.export_unit[g0 + i] = dst[(sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
+                    L.export_unit[g0 + i] = lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
                 }
             }
             __syncthreads();
@@ -594,20 +593,20 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     const int wave = tid >> 6;
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
-    _Float16* const buf[2] = {hl, hl + SB * PP * 2 * cph0};
-    const int cphs[2] = {cph0, cph1};
+    const int buf1_at = SB * PP * 2 * cph0;             // (offsets into hl, so that every access stays an LDS access)
     float* aconst = reinterpret_cast<float*>(hl + SB * PP * 2 * (cph0 + cph1));   // [SB] the constant plane's value
 
     auto plane_pos = [&](int p) { return (p / W + 1) * PW + (p % W) + 1; };
-    auto store_val = [&](_Float16* b, int cph, int pos, int n, float v) {
+    auto store_val = [&](int b, int cph, int pos, int n, float v) {       // b: the buffer's offset in hl
         const float vs = v * kActScale;
         const _Float16 h0 = static_cast<_Float16>(vs);
         const _Float16 h1 = static_cast<_Float16>(vs - static_cast<float>(h0));
-        b[pos * 2 * cph + n] = h0;
-        b[pos * 2 * cph + cph + n] = h1;
+        hl[b + pos * 2 * cph + n] = h0;
+        hl[b + pos * 2 * cph + cph + n] = h1;
     };
-    auto load_val = [&](const _Float16* b, int cph, int pos, int n) {
-        return (static_cast<float>(b[pos * 2 * cph + n]) + static_cast<float>(b[pos * 2 * cph + cph + n])) * (1.0f / kActScale);
+    auto load_val = [&](int b, int cph, int pos, int n) {
+        return (static_cast<float>(hl[b + pos * 2 * cph + n]) + static_cast<float>(hl[b + pos * 2 * cph + cph + n])) *
+               (1.0f / kActScale);
     };
 
     // ---- zero both buffers, then the tower's input (without the constant plane) into buffer 0 ---------------------
@@ -665,11 +664,36 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         pos_a[t] = (m / P) * PP + plane_pos(m % P);
     }
 
+    // plane position of the D rows this lane stores (row 4 kk + r of its tiles), -1 = not a row of a present sample
+    int pos_d[MTW][4];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int tile = row_group + t * RG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = tile * 16 + 4 * kk + r;
+            const bool ok = tile < MT && m < ROWS && m / P < n_samples;
+            pos_d[t][r] = ok ? (m / P) * PP + plane_pos(m % P) : -1;
+        }
+    }
+    // the first two weight groups of a layer are fetched before the previous layer's epilogue (L2 / HBM latency)
+    h8 bq[2][2];
+    auto wload_of = [&](const SplitLayer& layer, int it, int c, int q) {
+        const h8* w = reinterpret_cast<const h8*>(layer.wh) + kk * COUT + col_pair * 32 + i_row;
+        return w[(static_cast<size_t>(it) * 2 + q) * 4 * COUT + 16 * c];
+    };
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bq[c][q] = wload_of(args.layer[0], 0, c, q);
+        }
+
     for (int l = 0; l < args.n_layers; ++l) {
         const SplitLayer& L = args.layer[l];
-        const _Float16* in = buf[l & 1];
-        _Float16* dst = buf[(l & 1) ^ 1];
-        const int CPI = cphs[l & 1], CPO = cphs[(l & 1) ^ 1];
+        const int in = (l & 1) ? buf1_at : 0;            // offsets of the layer's input / output buffers in hl
+        const int dst = (l & 1) ? 0 : buf1_at;
+        const int CPI = (l & 1) ? cph1 : cph0, CPO = (l & 1) ? cph0 : cph1;
         const int ng = split_groups(L.cin);
         const int iterations = 9 * ng;
 
@@ -679,45 +703,34 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
 #pragma unroll
             for (int c = 0; c < 2; ++c) hi[t][c] = lo[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // lane (column n, kk) of column tile c reads half q of its 8 channels at wlane[(q * 4) * COUT * ... ] (16 bytes)
+        // Two register sets (operands of an even / an odd iteration), each refilled for iteration + 2 right after its MFMAs
+        // have issued: no register copies in the loop, LDS reads and weight loads one iteration ahead.
         const h8* wlane = reinterpret_cast<const h8*>(L.wh) + kk * COUT + col_pair * 32 + i_row;
         auto wload = [&](int it, int c, int q) { return wlane[(static_cast<size_t>(it) * 2 + q) * 4 * COUT + 16 * c]; };
-        int grp = 0, tap = 0;
+        int grp = 0, tap = 0;                            // the (tap, group) of the NEXT A fetch
         auto lds_offset = [&]() { return ((tap / 3 - 1) * PW + (tap % 3 - 1)) * 2 * CPI + grp * kSplitGroup + 8 * kk; };
         auto advance = [&]() {
             if (++grp == ng) {
                 grp = 0;
-                tap = tap < 8 ? tap + 1 : 8;
+                tap = tap < 8 ? tap + 1 : 8;             // (fetches past the last iteration re-read the last tap: unused)
             }
         };
-        h8 a[MTW][2], b[2][2], b1[2][2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                b[c][q] = wload(0, c, q);
-                b1[c][q] = wload(1, c, q);
-            }
-        {
+        h8 a_even[MTW][2], a_odd[MTW][2], w_even[2][2], w_odd[2][2];
+        auto fetch_a = [&](h8 (&a)[MTW][2]) {
             const int off = lds_offset();
 #pragma unroll
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) a[t][q] = *reinterpret_cast<const h8*>(in + pos_a[t] * 2 * CPI + q * CPI + off);
+                for (int q = 0; q < 2; ++q) a[t][q] = reinterpret_cast<const h8*>(hl)[(in + pos_a[t] * 2 * CPI + q * CPI + off) >> 3];
             advance();
-        }
-        for (int it = 0; it < iterations; ++it) {
-            h8 bn[2][2], an[MTW][2];
+        };
+        auto fetch_b = [&](h8 (&b)[2][2], int it) {      // (two spare zero groups follow the last iteration's weights)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bn[c][q] = wload(it + 2, c, q);   // (two spare zero groups follow the last)
-            const int off = lds_offset();
-#pragma unroll
-            for (int t = 0; t < MTW; ++t)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) an[t][q] = *reinterpret_cast<const h8*>(in + pos_a[t] * 2 * CPI + q * CPI + off);
-            advance();
+                for (int q = 0; q < 2; ++q) b[c][q] = wload(it, c, q);
+        };
+        auto multiply = [&](const h8 (&a)[MTW][2], const h8 (&b)[2][2]) {
 #pragma unroll
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
@@ -730,39 +743,54 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], b[c][0], lo[t][c], 0, 0, 0);
+        };
 #pragma unroll
-            for (int t = 0; t < MTW; ++t)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) a[t][q] = an[t][q];
+            for (int q = 0; q < 2; ++q) w_even[c][q] = bq[c][q];
+        fetch_b(w_odd, 1);
+        float sc2[2], sh2[2];                            // folded batch norm of this lane's two columns (in flight early)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            sc2[c] = L.scale[col_pair * 32 + c * 16 + i_row];
+            sh2[c] = L.shift[col_pair * 32 + c * 16 + i_row];
+        }
+        fetch_a(a_even);
+        fetch_a(a_odd);
+        for (int it = 0; it < iterations; it += 2) {     // (an odd count runs one more iteration on the spare zero weights)
+            multiply(a_even, w_even);
+            fetch_a(a_even);
+            fetch_b(w_even, min(it + 2, iterations + 1));
+            multiply(a_odd, w_odd);
+            fetch_a(a_odd);
+            fetch_b(w_odd, min(it + 3, iterations + 1));
+        }
+
+        if (l + 1 < args.n_layers) {                     // next layer's first weights: in flight under this epilogue
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    b[c][q] = b1[c][q];
-                    b1[c][q] = bn[c][q];
+                    bq[c][q] = wload_of(args.layer[l + 1], 0, c, q);
                 }
         }
-
         // ---- layer epilogue: D[row = 4 kk + r][col = lane & 15] of column tiles 2 col_pair, 2 col_pair + 1 --------------
         constexpr float kDescale = 1.0f / (kActScale * kWtScale);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int n = col_pair * 32 + c * 16 + i_row;
-            const float sc = L.scale[n], sh = L.shift[n];
 #pragma unroll
             for (int t = 0; t < MTW; ++t) {
-                const int tile = row_group + t * RG;
-                if (tile >= MT) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = tile * 16 + 4 * kk + r;
-                    if (m >= ROWS) continue;
-                    const int sidx = m / P, p = m % P;
-                    if (sidx >= n_samples) continue;
-                    const int pos = sidx * PP + plane_pos(p);
+                    const int pos = pos_d[t][r];
+                    if (pos < 0) continue;
                     float conv = (hi[t][c][r] + lo[t][c][r]) * kDescale;
-                    if (L.const_table) conv = conv + aconst[sidx] * L.const_table[n * P + p];
-                    float v = conv * sc + sh;
+                    if (L.const_table) {                 // (layer 0 only) position inside the board from the plane position
+                        const int pp = pos % PP;
+                        conv = conv + aconst[pos / PP] * L.const_table[n * P + (pp / PW - 1) * W + pp % PW - 1];
+                    }
+                    float v = conv * sc2[c] + sh2[c];
                     if (L.skip) v = v + load_val(dst, CPO, pos, n);
                     if (L.relu) v = v < 0.f ? 0.f : v;
                     store_val(dst, CPO, pos, n, v);

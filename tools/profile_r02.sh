@@ -3,6 +3,7 @@
 #   bench4     the four driver-runnable bench lines + the --gpus 2 self-launch rehearsal  -> gpurun_out/bench_<w>.json
 #   stats      rocprofv3 --kernel-trace --stats of each workload's bench command        -> gpurun_out/<w>_kernel_stats.csv
 #   fusedsq    SQ-counter passes of the fused CartPole kernel (2 passes x 8 counters)    -> gpurun_out/fused_sq.json
+#   mfma       matrix-pipe counters of the Connect4 network kernels                      -> gpurun_out/connect4_mfma_pmc.json
 #   traffic    FETCH_SIZE / WRITE_SIZE passes of the fused CartPole bench                -> gpurun_out/pmc_traffic_e4096.json
 # (the program goes directly after `--`; counters are collected in their own runs, with --kernel-trace only)
 set -e
@@ -40,6 +41,14 @@ fusedsq)
         $PY "$R/bench.py" --steps 20 --warmup 5 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 > "$R/gpurun_out/sq_b.log" 2>&1
     $PY "$R/tools/pmc_summary.py" /tmp/sq_a --sq 50 --top 4 > "$R/gpurun_out/fused_sq_insts.json"
     $PY "$R/tools/pmc_summary.py" /tmp/sq_b --sq 50 --top 4 > "$R/gpurun_out/fused_sq_waits.json"
+    ;;
+mfma)
+    # MFMA evidence for the Connect4 network path: matrix-pipe busy cycles / instruction mix per kernel
+    cd /tmp && export TMPDIR=/tmp
+    timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
+        --kernel-trace -d /tmp/mfma_c4 -o c4 --output-format csv -- \
+        $PY "$R/bench.py" --workload connect4 --steps 1 --warmup 1 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 --no-graph > "$R/gpurun_out/mfma_run.log" 2>&1
+    $PY "$R/tools/pmc_summary.py" /tmp/mfma_c4 --mfma --top 8 --tail 0.5 > "$R/gpurun_out/connect4_mfma_pmc.json"
     ;;
 traffic)
     cd /tmp && export TMPDIR=/tmp
