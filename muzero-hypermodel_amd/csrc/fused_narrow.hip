@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     for (int t = j; t < n_blocks * block_words; t += kRow) {
         const int k = t / block_words, i = t - k * block_words;
         const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
-        uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.block_stride);
+        uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.line_stride);   // own line, half 0
         dst[i] = src[i];
     }
     for (int t = j; t < n_blocks * enc; t += kRow) {

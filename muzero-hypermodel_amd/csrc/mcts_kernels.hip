@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
         n_root = p.root_children[e];
         mm = p.min_max[e];
         if (j == 0) mt_pos = p.mt_pos[e];
-        (void)*reinterpret_cast<const volatile int32_t*>(p.blocks + static_cast<size_t>(e) * p.block_stride + (16u * j) % p.block_stride);
+        (void)*reinterpret_cast<const volatile int32_t*>(p.blocks + static_cast<size_t>(e) * p.line_stride + (16u * j) % p.block_stride);
     }
     stage_pbc_table(pbc_table, p);
     __syncthreads();
@@ -89,6 +89,12 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
     if (j == 0) {
         p.path_len[e] = d.depth;
         p.leaf_parent[e] = d.parent;
+        // Where the node this simulation expands will live: normally line (sim + 1, e); with paired lines the FIRST
+        // child a node expands (the node has not been descended through before: one visit, none for the root) takes the
+        // free half of that node's own line, if the node owns its line (is not itself such a guest).
+        const bool first_child = d.parent_visits == (d.parent == 0 ? 0 : 1);
+        const bool paired = p.line_stride != p.block_stride;
+        p.leaf_loc[e] = (paired && first_child && (d.parent_loc & 1) == 0) ? (d.parent_loc | 1) : 2 * (sim + 1);
         if (words) {
             p.mt_pos[e] = mt_pos;
             p.tie_words[e] += words;
@@ -266,13 +272,14 @@ __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, i
     if (!INJECTED) group_softmax<G, CH>(logit, valid, prior);
 
     const GlobalTree tree = global_tree(p, e);
-    write_children<G, CH>(tree, sim + 1, p.A, prior, j);  // slab sim+1 is contiguous over trees
+    const int loc_new = p.leaf_loc[e];                   // chosen by select (own line of slab sim + 1, or the parent's)
+    write_children<G, CH>(tree, loc_new, p.A, prior, j);
 
     MinMax mm = p.min_max[e];
     double root_value_sum = (j == 0) ? p.root_value_sum[e] : 0.0;
     const double root_reward = (j == 0) ? p.root_reward[e] : 0.0;
     backup<G>(tree, depth, sim, value, reward_f, p.P == 2, p.discount, mm, root_value_sum, root_reward,
-              staged[tree_in_block], j);
+              staged[tree_in_block], j, loc_new);
     if (j == 0) {
         p.root_value_sum[e] = root_value_sum;
         p.min_max[e] = mm;
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         group_softmax<G, CH>(logit, valid, prior);
         MZ_STAMP(4);
         const int k_new = sim + 1;
-        write_children<G, CH>(tree, k_new, p.A, prior, j);
+        write_children<G, CH>(tree, 2 * k_new, p.A, prior, j);   // (a tree in LDS keeps block k at slab k)
         for (int i = j; i < H; i += G) {
             const float h = scratch[net.off_norm + i];
             if (hidden_in_lds) hidden_lds[static_cast<size_t>(k_new) * H + i] = h;
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         MZ_STAMP(5);
         // the activation scratch is dead once the heads are decoded: it doubles as the backup's hand-over area
         backup<G>(tree, d.depth, sim, value, reward_f, two_player, p.discount, mm, root_value_sum, root_reward,
-                  reinterpret_cast<StagedNode*>(scratch), j);
+                  reinterpret_cast<StagedNode*>(scratch), j, 2 * k_new);
         group_memory_fence();
         // the leader owns the running min-max statistics; every lane scores its child with them
         mm.minimum = __shfl(mm.minimum, 0, G);
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
     const int block_words = static_cast<int>(p.block_stride / 16);
     for (int k = 0; k <= n_sims; ++k) {
         const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
-        uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.block_stride);
+        uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.line_stride);   // own line, half 0
         for (int i = j; i < block_words; i += G) dst[i] = src[i];
     }
     MZ_STAMP(7);
@@ -560,7 +567,9 @@ static void dispatch_group(const TreeParams& p, Fn&& fn) {
         return;
     }
     switch (p.group) {
-        case 1: fn(IntC<1>{}, IntC<1>{}); break;
+        case 1:
+            if (p.chunks == 2) fn(IntC<1>{}, IntC<2>{}); else fn(IntC<1>{}, IntC<1>{});
+            break;
         case 2: fn(IntC<2>{}, IntC<1>{}); break;
         case 4: fn(IntC<4>{}, IntC<1>{}); break;
         case 8: fn(IntC<8>{}, IntC<1>{}); break;

@@ -51,7 +51,12 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     p.H = H;
     p.chunks = A > 64 ? (A + 63) / 64 : 1;
     p.group = mz::default_group_width(A);
-    if (c->group_width != 0) {
+    if (c->group_width == 1 && A == 2) {
+        // one lane per tree, the lane loops over the two children: twice the trees (memory requests in flight) per
+        // wavefront of the lock-step kernels, whose descents are chains of dependent loads
+        p.group = 1;
+        p.chunks = 2;
+    } else if (c->group_width != 0) {
         const int g = c->group_width;
         if (g < p.group || g > 64 || (g & (g - 1)) != 0) {
             delete eng;
@@ -61,6 +66,8 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     }
     p.links_offset = 16u * static_cast<uint32_t>(A);
     p.block_stride = mz::round_up(32u * static_cast<uint32_t>(A), 64u);
+    // 64-byte blocks (A <= 2) come two to a 128-byte line: a node's first-expanded child shares the node's line
+    p.line_stride = p.block_stride == 64u ? 128u : p.block_stride;
     p.discount = c->discount;
     p.noise_frac = c->root_exploration_fraction;
 
@@ -73,7 +80,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         return code;
     };
     const size_t K = static_cast<size_t>(S) + 1;
-    if ((rc = dev_alloc(eng, &p.blocks, K * E * p.block_stride))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.blocks, K * E * p.line_stride))) return cleanup_on(rc);
     if (c->hidden_pool) {
         p.hidden = static_cast<float*>(c->hidden_pool);
     } else {
@@ -84,6 +91,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     p.path_ties = nullptr;
     if ((rc = dev_alloc(eng, &p.path_len, E))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &p.leaf_parent, E))) return cleanup_on(rc);
+    if ((rc = dev_alloc(eng, &p.leaf_loc, E))) return cleanup_on(rc);
     if ((rc = dev_alloc(eng, &p.root_reward, E))) return cleanup_on(rc);
     {
         // per-move upload block: [legal i32 E*A | num_legal i32 E | to_play i32 E | rng_skip u32 E | noise f64 E*A]
@@ -153,7 +161,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         p.pbc_sqrt = d_tab + K;
     }
 
-    if ((rc = pinned_alloc(eng, &eng->h_slab0, static_cast<size_t>(E) * p.block_stride))) return cleanup_on(rc);
+    if ((rc = pinned_alloc(eng, &eng->h_slab0, static_cast<size_t>(E) * p.line_stride))) return cleanup_on(rc);
 
     eng->streams.resize(E);
     eng->lag.assign(E, 0u);
@@ -397,7 +405,7 @@ int mzmcts_set_simulations_done(mzmcts_engine* eng, int32_t n) {
 
 static int enqueue_readout_copies(mzmcts_engine* eng, hipStream_t stream) {
     const mz::TreeParams& p = eng->p;
-    MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(p.E) * p.block_stride, hipMemcpyDeviceToHost, stream));
+    MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(p.E) * p.line_stride, hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipMemcpyAsync(eng->h_download, eng->d_download, eng->download_bytes, hipMemcpyDeviceToHost, stream));
     return MZMCTS_OK;
 }
@@ -440,7 +448,7 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
     eng->for_each_env([&](int lo, int hi) {
         int64_t local_depth = 0, local_active = 0;
         for (int e = lo; e < hi; ++e) {
-            const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.block_stride;
+            const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.line_stride;   // the root's block: half 0 of line (0, e)
             const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
             const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
             const int n = eng->h_nlegal[e];
@@ -560,7 +568,7 @@ int mzmcts_last_paths(mzmcts_engine* eng, int32_t* depth, int32_t* actions, int3
         for (int d = 0; d < S; ++d) {
             const size_t o = static_cast<size_t>(e) * S + d;
             if (d < depth[e]) {
-                const int slot = path[static_cast<size_t>(d) * E + e] & 0xffff;
+                const int slot = path[static_cast<size_t>(d) * E + e] & 0xff;
                 if (actions) actions[o] = (d == 0) ? eng->h_legal[static_cast<size_t>(e) * A + slot] : slot;
                 if (tie_counts) tie_counts[o] = ties.empty() ? -1 : ties[static_cast<size_t>(d) * E + e];
             } else {
@@ -581,17 +589,25 @@ int mzmcts_export_tree(mzmcts_engine* eng, int32_t env, int32_t* visits, double*
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const mz::TreeParams& p = eng->p;
     const int K = p.S + 1, A = p.A;
-    std::vector<uint8_t> buf(static_cast<size_t>(K) * p.block_stride);
-    MZ_HIP(eng, hipMemcpy2DAsync(buf.data(), p.block_stride, p.blocks + static_cast<size_t>(env) * p.block_stride,
-                                 static_cast<size_t>(p.E) * p.block_stride, p.block_stride, K, hipMemcpyDeviceToHost,
+    // the tree's lines (one per slab); node k's block sits where its parent's link says (block_loc = 2 * slab + half)
+    std::vector<uint8_t> buf(static_cast<size_t>(K) * p.line_stride);
+    MZ_HIP(eng, hipMemcpy2DAsync(buf.data(), p.line_stride, p.blocks + static_cast<size_t>(env) * p.line_stride,
+                                 static_cast<size_t>(p.E) * p.line_stride, p.line_stride, K, hipMemcpyDeviceToHost,
                                  stream));
     MZ_HIP(eng, hipStreamSynchronize(stream));
     const int n_root = eng->h_nlegal[env];
+    std::vector<int32_t> loc_of(static_cast<size_t>(K), -1);
+    loc_of[0] = 0;
     for (int k = 0; k < K; ++k) {
-        const uint8_t* blk = buf.data() + static_cast<size_t>(k) * p.block_stride;
+        const int loc = loc_of[k];                       // (parents have smaller expansion indices than their children)
+        const bool placed = loc >= 0 && (loc >> 1) < K;
+        const uint8_t* blk = buf.data() + static_cast<size_t>(placed ? (loc >> 1) : 0) * p.line_stride + (placed ? (loc & 1) * 64u : 0u);
         const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
         const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
-        const bool written = k <= eng->sim;
+        if (placed && k <= eng->sim)
+            for (int i = 0; i < (k == 0 ? n_root : A); ++i)
+                if (lk[i].child_node > k && lk[i].child_node < K) loc_of[lk[i].child_node] = lk[i].block_loc;
+        const bool written = placed && k <= eng->sim;
         for (int i = 0; i < A; ++i) {
             const size_t o = static_cast<size_t>(k) * A + i;
             const bool live = written && (k > 0 || i < n_root);

@@ -574,7 +574,7 @@ __device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int s
             const double seen = r + discount * (two_player ? -q : q);
             st->value_sum = vs_new;
             if (leaf)
-                *lk = ChildLinks{reward_f, 1, k_new, 0};
+                *lk = ChildLinks{reward_f, 1, k_new, 2 * k_new};   // (published trees keep block k at slab k, half 0)
             else
                 lk->visits = visits_new;
             acc.vterm(kk)[slot] = seen;

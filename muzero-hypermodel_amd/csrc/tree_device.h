@@ -86,18 +86,20 @@ __device__ __forceinline__ void group_memory_fence() {
 }
 
 // ---- storage policies ---------------------------------------------------------------------------
+// Blocks are addressed by LOCATION loc = 2 * slab + half (ChildLinks::block_loc); the root's is 0.
 struct GlobalTree {
     static constexpr bool kInLds = false;
-    uint8_t* blocks;       // p.blocks + e * block_stride
-    size_t slab_stride;    // E * block_stride
+    uint8_t* blocks;       // p.blocks + e * line_stride
+    size_t slab_stride;    // E * line_stride
     uint32_t links_offset;
     int32_t* path;         // p.path + e
     int E;
-    __device__ __forceinline__ ChildStats* stats(int k) const {
-        return reinterpret_cast<ChildStats*>(blocks + static_cast<size_t>(k) * slab_stride);
+    __device__ __forceinline__ uint8_t* block(int loc) const {
+        return blocks + static_cast<size_t>(loc >> 1) * slab_stride + static_cast<size_t>(loc & 1) * 64u;
     }
-    __device__ __forceinline__ ChildLinks* links(int k) const {
-        return reinterpret_cast<ChildLinks*>(blocks + static_cast<size_t>(k) * slab_stride + links_offset);
+    __device__ __forceinline__ ChildStats* stats(int loc) const { return reinterpret_cast<ChildStats*>(block(loc)); }
+    __device__ __forceinline__ ChildLinks* links(int loc) const {
+        return reinterpret_cast<ChildLinks*>(block(loc) + links_offset);
     }
     __device__ __forceinline__ void path_store(int level, int packed) const {
         path[static_cast<size_t>(level) * E] = packed;
@@ -106,7 +108,7 @@ struct GlobalTree {
 };
 
 __device__ __forceinline__ GlobalTree global_tree(const TreeParams& p, int e) {
-    return GlobalTree{p.blocks + static_cast<size_t>(e) * p.block_stride, static_cast<size_t>(p.E) * p.block_stride,
+    return GlobalTree{p.blocks + static_cast<size_t>(e) * p.line_stride, static_cast<size_t>(p.E) * p.line_stride,
                       p.links_offset, p.path + e, p.E};
 }
 
@@ -116,11 +118,12 @@ struct LdsTree {
     uint32_t block_stride;
     uint32_t links_offset;
     int32_t* path;         // this tree's S path words in LDS
-    __device__ __forceinline__ ChildStats* stats(int k) const {
-        return reinterpret_cast<ChildStats*>(blocks + static_cast<uint32_t>(k) * block_stride);
+    // (a tree in LDS keeps block k at slab k: loc = 2 k)
+    __device__ __forceinline__ ChildStats* stats(int loc) const {
+        return reinterpret_cast<ChildStats*>(blocks + static_cast<uint32_t>(loc >> 1) * block_stride);
     }
-    __device__ __forceinline__ ChildLinks* links(int k) const {
-        return reinterpret_cast<ChildLinks*>(blocks + static_cast<uint32_t>(k) * block_stride + links_offset);
+    __device__ __forceinline__ ChildLinks* links(int loc) const {
+        return reinterpret_cast<ChildLinks*>(blocks + static_cast<uint32_t>(loc >> 1) * block_stride + links_offset);
     }
     __device__ __forceinline__ void path_store(int level, int packed) const { path[level] = packed; }
     __device__ __forceinline__ int path_load(int level) const { return path[level]; }
@@ -147,6 +150,8 @@ struct Descent {
     int depth;        // number of select steps == tree depth of the leaf
     int parent;       // expanded-node index of the leaf's parent (its hidden-state slab)
     int slot;         // child slot of the leaf inside its parent's block
+    int parent_loc;   // block location of the leaf's parent
+    int parent_visits;  // its visit count before this simulation
 };
 
 // The `while node.expanded()` loop (self_play.py:321-335) with select_child (self_play.py:364-379).
@@ -161,12 +166,13 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
     while (span < A && span < G) span <<= 1;
     int n_children = n_root_children;
     int k = 0;    // expanded-node index of the current parent
+    int loc = 0;  // where its block lives
     int N = sim;  // its visit count: the root has been visited once per finished simulation
     int depth = 0;
     int slot = 0;
     for (;;) {
-        const ChildStats* stats = acc.stats(k);
-        const ChildLinks* links = acc.links(k);
+        const ChildStats* stats = acc.stats(loc);
+        const ChildLinks* links = acc.links(loc);
         const double pb_log = pbc_table[N];
         const double pb_sqrt = pbc_table[S + 1 + N];
 
@@ -209,7 +215,7 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
             if (j == 0) atomicOr(error_flag, 1);
             tie_mask[0] = 1ull;
         }
-        int sel_visits = 0, sel_child = -1;
+        int sel_visits = 0, sel_child = -1, sel_loc = 0;
         {
             int remaining = pick;
             bool found = false;
@@ -225,16 +231,20 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
                     // moves (child_node is biased by 1 so that "not expanded" (-1) contributes zero bits)
                     int pub_visits = (j == bit) ? lk[c].visits : 0;
                     int pub_child = (j == bit) ? lk[c].child_node + 1 : 0;
+                    int pub_loc = (j == bit) ? lk[c].block_loc : 0;
                     if constexpr (G <= 16) {
                         // over the whole group, so that every lane ends up with the values
                         MZ_BUTTERFLY(G, G, (pub_visits |= partner_bits<M>(pub_visits),
-                                            pub_child |= partner_bits<M>(pub_child)));
+                                            pub_child |= partner_bits<M>(pub_child),
+                                            pub_loc |= partner_bits<M>(pub_loc)));
                     } else {
                         pub_visits = __shfl(lk[c].visits, bit, G);
                         pub_child = __shfl(lk[c].child_node, bit, G) + 1;
+                        pub_loc = __shfl(lk[c].block_loc, bit, G);
                     }
                     sel_visits = pub_visits;
                     sel_child = pub_child - 1;
+                    sel_loc = pub_loc;
                     found = true;
                 } else if (!found) {
                     remaining -= cnt;  // (found / remaining are uniform across the group's lanes)
@@ -242,7 +252,7 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
             }
         }
         if (j == 0) {
-            acc.path_store(depth, (k << 16) | slot);
+            acc.path_store(depth, (loc << 8) | slot);
             if (path_ties) path_ties[static_cast<size_t>(depth) * ties_stride] = n_ties;
         }
         ++depth;
@@ -252,10 +262,11 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
             break;
         }
         k = sel_child;
+        loc = sel_loc;
         N = sel_visits;
         n_children = A;
     }
-    return Descent{depth, k, slot};
+    return Descent{depth, k, slot, loc, N};
 }
 
 // models.py:656-661: invert the value scaling, fp32, torch's operation order.
@@ -370,9 +381,9 @@ __device__ __forceinline__ void group_softmax(const float (&logit)[CH], const bo
 
 // node.expand over the full action space (self_play.py:346-352, 452-466): children of node k_new.
 template <int G, int CH, typename Acc>
-__device__ __forceinline__ void write_children(const Acc& acc, int k_new, int A, const double (&prior)[CH], int j) {
-    ChildStats* stats = acc.stats(k_new);
-    ChildLinks* links = acc.links(k_new);
+__device__ __forceinline__ void write_children(const Acc& acc, int loc_new, int A, const double (&prior)[CH], int j) {
+    ChildStats* stats = acc.stats(loc_new);
+    ChildLinks* links = acc.links(loc_new);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int child = c * G + j;
@@ -419,18 +430,18 @@ __device__ __forceinline__ void backup_step(double& value_sum, int32_t& visits, 
 template <int G, typename Acc>
 __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, double value, float reward_f, bool two_player,
                                        double discount, MinMax& mm, double& root_value_sum, double root_reward,
-                                       StagedNode* staged, int j) {
+                                       StagedNode* staged, int j, int loc_new) {
     const int k_new = sim + 1;
     const double reward = static_cast<double>(reward_f);
     // leaf (tree depth == depth): first visit, value_sum was 0; it is `to_play`'s own node
     if (j == 0) {
         const int packed = acc.path_load(depth - 1);
-        const int slot = packed & 0xffff;
-        ChildStats* st = acc.stats(packed >> 16) + slot;
-        ChildLinks* lk = acc.links(packed >> 16) + slot;
+        const int slot = packed & 0xff;
+        ChildStats* st = acc.stats(packed >> 8) + slot;
+        ChildLinks* lk = acc.links(packed >> 8) + slot;
         const double vs = 0.0 + value;
         st->value_sum = vs;
-        *lk = ChildLinks{reward_f, 1, k_new, 0};
+        *lk = ChildLinks{reward_f, 1, k_new, loc_new};
         const double q = vs / 1.0;
         const double seen = two_player ? (reward + discount * -q) : (reward + discount * q);
         mm.maximum = fmax(mm.maximum, seen);
@@ -457,9 +468,9 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
             ChildLinks l{0.f, 0, -1, 0};
             if (mine) {
                 const int packed = acc.path_load(level);
-                const int slot = packed & 0xffff;
-                st = acc.stats(packed >> 16) + slot;
-                lk = acc.links(packed >> 16) + slot;
+                const int slot = packed & 0xff;
+                st = acc.stats(packed >> 8) + slot;
+                lk = acc.links(packed >> 8) + slot;
                 vs = st->value_sum;
                 l = *lk;
                 r_buf[j] = l.reward;
@@ -499,12 +510,30 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
     } else {
         for (int hi = depth - 2; hi >= 0; hi -= kStageLevels) {
             const int count = (hi + 1 < kStageLevels) ? hi + 1 : kStageLevels;  // levels hi, hi-1, ...
-            for (int i = j; i < count; i += G) {
-                const int packed = acc.path_load(hi - i);
-                const int slot = packed & 0xffff;
-                const ChildStats* st = acc.stats(packed >> 16) + slot;
-                const ChildLinks lk = *(acc.links(packed >> 16) + slot);
-                staged[i] = StagedNode{st->value_sum, lk.reward, lk.visits};
+            // every lane's path words first, then every record: all of a tree's loads are in flight together (at HBM scale
+            // each is a DRAM round trip of microseconds; issued one per loop iteration they would queue up behind each other)
+            constexpr int kPer = (kStageLevels + G - 1) / G;
+            int packed_u[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = j + u * G;
+                packed_u[u] = (i < count) ? acc.path_load(hi - i) : 0;
+            }
+            double vs_u[kPer];
+            ChildLinks lk_u[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = j + u * G;
+                if (i < count) {
+                    const int slot = packed_u[u] & 0xff;
+                    vs_u[u] = (acc.stats(packed_u[u] >> 8) + slot)->value_sum;
+                    lk_u[u] = *(acc.links(packed_u[u] >> 8) + slot);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = j + u * G;
+                if (i < count) staged[i] = StagedNode{vs_u[u], lk_u[u].reward, lk_u[u].visits};
             }
             group_memory_fence();
             if (j == 0) {
@@ -518,12 +547,15 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
                 }
             }
             group_memory_fence();
-            for (int i = j; i < count; i += G) {
-                const int packed = acc.path_load(hi - i);
-                const int slot = packed & 0xffff;
-                const StagedNode n = staged[i];
-                (acc.stats(packed >> 16) + slot)->value_sum = n.value_sum;
-                (acc.links(packed >> 16) + slot)->visits = n.visits;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = j + u * G;
+                if (i < count) {
+                    const int slot = packed_u[u] & 0xff;
+                    const StagedNode n = staged[i];
+                    (acc.stats(packed_u[u] >> 8) + slot)->value_sum = n.value_sum;
+                    (acc.links(packed_u[u] >> 8) + slot)->visits = n.visits;
+                }
             }
             group_memory_fence();
         }

@@ -4,7 +4,11 @@
 // so "expanded node k" (k = 0 for the root, k = s+1 for the node expanded by simulation s) is a
 // dense index shared by all trees, and every pool is laid out [k][e][...]:
 //
-//   child blocks   [(S+1)][E] blocks of `block_stride` bytes.  Block (k,e) holds the A children of
+//   child blocks   [(S+1)][E] lines of `line_stride` bytes.  A node's block is found through its parent's link
+//                  (ChildLinks::block_loc = 2 * slab + half): normally line (k, e) of its own expansion index k,
+//                  half 0; with 64-byte blocks (A <= 2) the FIRST child a node expands moves into the free second
+//                  half of that node's line instead (when the node owns its line), so that the most frequent hop of
+//                  a descent (65 % on the CartPole traces) needs no new 128-byte line.  Block (k,e) holds the A children of
 //                  expanded node k of tree e as two 16-byte-wide member arrays (struct-of-arrays
 //                  inside the block, so one lane per child reads two fully coalesced dwordx4):
 //                      ChildStats stats[A]   { f64 value_sum; f64 prior }
@@ -35,7 +39,7 @@ struct alignas(16) ChildLinks {
     float reward;        // Node.reward: always an fp32 value (.item() of an fp32 tensor, self_play.py:345)
     int32_t visits;      // Node.visit_count
     int32_t child_node;  // expanded-node index of this child, -1 while it is a leaf (not expanded)
-    int32_t pad;
+    int32_t block_loc;   // where the child's own block lives: 2 * (slab index) + (half of the line), see line_stride
 };
 
 struct alignas(16) MinMax {
@@ -48,6 +52,11 @@ struct TreeParams {
     int32_t group;           // lanes per tree: pow2 >= min(A, 64), one wavefront holds 64/group trees
     uint32_t block_stride;   // bytes per child block
     uint32_t links_offset;   // 16 * A
+    uint32_t line_stride;    // HBM pool: bytes between the lines of consecutive trees in a slab.  = block_stride, or
+                             // 128 when a 64-byte block shares its line with the block of its node's first-expanded
+                             // child (A <= 2): the memory system fetches 128-byte lines whatever a request asks for
+                             // (profiles/r02_record_size_ceiling.jsonl), so the most likely next hop rides along
+    int32_t* leaf_loc;       // [E] block location select chose for the node the coming expand_backup creates
     double discount;
     double noise_frac;
     // pools

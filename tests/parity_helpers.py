@@ -159,7 +159,7 @@ def _result_arrays(T, A, S):
 
 
 def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="cuda", temperature=1.0,
-                           record_paths=True, repeat=1, engine=None):
+                           record_paths=True, repeat=1, engine=None, group_width=0):
     """Drive the HIP engine through the C ABI with injected streams.
 
     `repeat` tiles the T trees `repeat` times (env e replays stream e % T), which exercises batching:
@@ -175,7 +175,7 @@ def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="
     A, S = len(config.action_space), config.num_simulations
     own = engine is None
     if own:
-        engine = engine_mod.BatchedMCTS(config, E, device=device, seeds=streams["seeds"] * repeat)
+        engine = engine_mod.BatchedMCTS(config, E, device=device, seeds=streams["seeds"] * repeat, group_width=group_width)
     else:
         engine.seed(streams["seeds"] * repeat)
     if record_paths:

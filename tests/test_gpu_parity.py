@@ -75,6 +75,21 @@ def test_injected_traces_bit_exact_vs_reference_and_oracle(eng, oracle, name):
     assert np.array_equal(got["depth_sum"], fx["sim_depth"].sum(axis=1))
 
 
+@pytest.mark.parametrize("name", ["g4_cartpole_traces", "g5_cartpole_ties_traces"])
+def test_injected_traces_one_lane_per_tree(eng, oracle, name):
+    """group_width = 1 (two-action games): one lane owns a tree and loops over its children -- twice the trees per
+    wavefront for the HBM-scale lock-step kernels.  Same bits as the reference's traces."""
+    fx = load_golden(name)
+    idx = list(range(len(fx["seed"])))
+    temps = fx["temperature"].tolist()
+    got = run_injected_on_engine(eng, None, fx, idx, temperature=temps, group_width=1)
+    want = run_injected_on_oracle(oracle, fx, idx=idx, temperature=temps)
+    assert_exact(got, want, where=f"{name} (one lane per tree) vs oracle: ")
+    for key in ("noise", "visits", "child_value_sum", "child_prior", "child_reward"):
+        assert np.array_equal(got[key], fx[key]), key
+    assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, : int(fx["cfg_S"])])
+
+
 def test_injected_batching_independence(eng):
     """4096 trees = the 32 CartPole traces tiled 128x: every copy must be identical to the first."""
     fx = load_golden("g4_cartpole_traces")

@@ -4,7 +4,7 @@ hidden pools exceed 512 MB").  Injected network outputs (no inference), CartPole
 (A=2, S=50, H=8), E trees; prints per-kernel mean duration (HIP events bound to the dispatch) and the
 achieved algorithmic GB/s against the 8 TB/s HBM roofline, as one JSON line.
 
-    python tools/roofline_large_e.py [log2_E=20] [A=2] [S=50] [H=8]
+    python tools/roofline_large_e.py [log2_E=20] [A=2] [S=50] [H=8] [lanes per tree]
 """
 import importlib, json, os, sys, time
 import numpy as np, torch
@@ -16,11 +16,12 @@ log2e = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 A = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+GROUP = int(sys.argv[5]) if len(sys.argv) > 5 else 0     # lanes per tree (0 = default; 1 = one lane per tree, A = 2)
 E = 1 << log2e
 eng = importlib.import_module("muzero-hypermodel_amd.engine")
 cfg = make_search_config(A, S, 1 if A == 2 else 2, 0.997, H=H)
 t0 = time.time()
-engine = eng.BatchedMCTS(cfg, E)
+engine = eng.BatchedMCTS(cfg, E, group_width=GROUP)
 print(f"engine for E={E} built in {time.time()-t0:.1f}s, device pools {engine.device_bytes()/2**30:.2f} GiB", flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 value = (torch.randn(E, generator=g, device="cuda", dtype=torch.float32) * 30).double()
@@ -47,7 +48,7 @@ torch.cuda.synchronize()
 prof = engine.get_profile(reset=True)
 d = prof["select_depth_sum"] / max(prof["simulations"], 1)
 b = engine.algorithmic_bytes_per_simulation(d)
-out = {"E": E, "A": A, "S": S, "H": H, "mean_select_depth": d, "device_pool_GiB": engine.device_bytes() / 2**30, "kernels": {}}
+out = {"lanes_per_tree": engine.group_width() if GROUP != 1 else 1, "E": E, "A": A, "S": S, "H": H, "mean_select_depth": d, "device_pool_GiB": engine.device_bytes() / 2**30, "kernels": {}}
 for name, ms, n, per in (("select", "select_ms", "select_launches", b["select"]), ("expand_backup", "expand_backup_ms", "expand_backup_launches", b["expand_backup"])):
     us = 1e3 * prof[ms] / prof[n]
     out["kernels"][name] = {"avg_us": us, "launches": prof[n], "algorithmic_bytes_per_launch": per * E,
