@@ -947,14 +947,14 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     const int b = static_cast<int>(batch);
     if (height == 6 && width == 7) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream);
-        return mz::launch_board_tower<1, 6, 7, 8>(x, b, cin0, args, stream);
+        return mz::launch_board_tower<1, 6, 7, 4>(x, b, cin0, args, stream);
     }
     if (height == 6 && width == 6) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream);
-        return mz::launch_board_tower<1, 6, 6, 8>(x, b, cin0, args, stream);
+        return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream);
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
-    return mz::launch_board_tower<1, 3, 3, 32>(x, b, cin0, args, stream);
+    return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream);
 }
 
 extern "C" int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout) {

@@ -592,6 +592,13 @@ class DownsampleCNN(torch.nn.Module):
         self.avgpool = torch.nn.AdaptiveAvgPool2d(h_w)
 
     def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            # MIOpen's immediate mode falls back to a per-image im2col + GEMM loop for these shapes (12 x 12 kernel, stride
+            # 4 on 84 x 84 frames): two launches per image, 57 % of the GPU time of an Atari-like search at 1024 envs
+            # (profiles/r02_bench_atari84_kernel_stats.csv).  Letting it search once per shape picks a batched solver
+            # (0.36 ms for 1024 frames).
+            with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+                return self.avgpool(self.features(x))
         return self.avgpool(self.features(x))
 
 
