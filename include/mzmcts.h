@@ -332,6 +332,11 @@ int mzmcts_conv_head(const float *x, const mzmcts_head_desc *head, float *out, i
  * outs[h] dev f32[batch, heads[h].outputs]; all heads share channels and plane. */
 int mzmcts_conv_heads(const float *x, const mzmcts_head_desc *heads, int32_t n_heads, float *const *outs,
                       int64_t batch, void *stream);
+/* n_heads (1..3) heads in one launch, head h reading its OWN tensor xs[h] (the reward head reads the dynamics
+ * network's raw output, value and policy the prediction network's: models.py:467-480, 500-522); all heads share
+ * channels and plane. */
+int mzmcts_conv_heads_multi(const float *const *xs, const mzmcts_head_desc *heads, int32_t n_heads, float *const *outs,
+                            int64_t batch, void *stream);
 
 /* ---- 3x3 board convolution on the matrix cores, epilogue fused -------------------------------
  * out = act( conv3x3(x, weight; padding 1, stride 1, no bias) * scale[c] + shift[c] (+ residual) ): Conv2d ->

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "mzmcts_state_action_planes": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_int32, c_void]),
     "mzmcts_conv_heads": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void, ctypes.c_int64, c_void]),
+    "mzmcts_conv_heads_multi": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void, ctypes.c_int64, c_void]),
     "mzmcts_conv_head": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "mzmcts_unit_rescale": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_packed_floats": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),

@@ -145,14 +145,16 @@ __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__
 }
 
 // Up to two heads that read the same board (value and policy) share a launch: blockIdx.y picks the head.
-constexpr int kMaxHeads = 2;
+constexpr int kMaxHeads = 3;
 struct HeadSet {
+    const float* x[kMaxHeads];   // the tensor each head reads (value / policy share one, the reward head has its own)
     mzmcts_head_desc desc[kMaxHeads];
     HeadShape shape[kMaxHeads];
     float* out[kMaxHeads];
 };
 
-__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(const float* __restrict__ x, HeadSet set, int batch) {
+__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(HeadSet set, int batch) {
+    const float* __restrict__ x = set.x[blockIdx.y];
     const mzmcts_head_desc d = set.desc[blockIdx.y];
     const HeadShape s = set.shape[blockIdx.y];
     float* __restrict__ out = set.out[blockIdx.y];
@@ -300,11 +302,12 @@ extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
-extern "C" int mzmcts_conv_heads(const float* x, const mzmcts_head_desc* heads, int32_t n_heads, float* const* outs,
-                                 int64_t batch, void* stream_) {
-    if (!x || !heads || !outs || n_heads < 1 || n_heads > mz::kMaxHeads || batch < 0 || batch > 0x7fffffff ||
-        (reinterpret_cast<uintptr_t>(x) & 15u))
+extern "C" int mzmcts_conv_heads_multi(const float* const* xs, const mzmcts_head_desc* heads, int32_t n_heads,
+                                       float* const* outs, int64_t batch, void* stream_) {
+    if (!xs || !heads || !outs || n_heads < 1 || n_heads > mz::kMaxHeads || batch < 0 || batch > 0x7fffffff)
         return MZMCTS_ERR_INVALID;
+    for (int h = 0; h < n_heads; ++h)
+        if (!xs[h] || (reinterpret_cast<uintptr_t>(xs[h]) & 15u)) return MZMCTS_ERR_INVALID;
     mz::HeadSet set{};
     size_t lds = 0;
     for (int h = 0; h < n_heads; ++h) {
@@ -315,6 +318,7 @@ extern "C" int mzmcts_conv_heads(const float* x, const mzmcts_head_desc* heads, 
             return MZMCTS_ERR_INVALID;
         int split = 1;
         while (split * 2 * d->hidden <= 64) split *= 2;  // lanes per hidden unit (a power of two; 1 from 33 units on)
+        set.x[h] = xs[h];
         set.desc[h] = *d;
         set.shape[h] = mz::HeadShape{d->channels, d->plane, d->reduced, d->hidden, d->outputs, split};
         set.out[h] = outs[h];
@@ -330,9 +334,16 @@ extern "C" int mzmcts_conv_heads(const float* x, const mzmcts_head_desc* heads, 
     const int64_t rounds = (batch + mz::kHeadWaves - 1) / mz::kHeadWaves;
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
     const dim3 grid(static_cast<unsigned>(std::min<int64_t>(rounds, 256 * per_cu)), static_cast<unsigned>(n_heads));
-    mz::conv_head_kernel<<<grid, dim3(64 * mz::kHeadWaves), lds, static_cast<hipStream_t>(stream_)>>>(x, set,
+    mz::conv_head_kernel<<<grid, dim3(64 * mz::kHeadWaves), lds, static_cast<hipStream_t>(stream_)>>>(set,
                                                                                                     static_cast<int>(batch));
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+extern "C" int mzmcts_conv_heads(const float* x, const mzmcts_head_desc* heads, int32_t n_heads, float* const* outs,
+                                 int64_t batch, void* stream) {
+    if (n_heads < 1 || n_heads > mz::kMaxHeads) return MZMCTS_ERR_INVALID;
+    const float* xs[mz::kMaxHeads] = {x, x, x};
+    return mzmcts_conv_heads_multi(xs, heads, n_heads, outs, batch, stream);
 }
 
 extern "C" int mzmcts_conv_head(const float* x, const mzmcts_head_desc* d, float* out, int64_t batch, void* stream) {

@@ -332,6 +332,34 @@ def conv_heads(x, heads):
     return [fc(conv(x).reshape(-1, flat_size)) for conv, fc, flat_size in heads]
 
 
+def conv_heads_multi(inputs_and_heads):
+    """[fc(conv(x).reshape(-1, flat_size)) for x, (conv, fc, flat_size) in inputs_and_heads] with up to three heads that
+    read DIFFERENT tensors of one shape in ONE HIP launch (include/mzmcts.h mzmcts_conv_heads_multi): the reward head on
+    the dynamics network's raw output next to the value / policy heads on the prediction network's features."""
+    xs = [x for x, _ in inputs_and_heads]
+    heads = [h for _, h in inputs_and_heads]
+    if (1 <= len(heads) <= 3 and all(_head_is_native(x, conv, fc) for x, (conv, fc, _) in inputs_and_heads)
+            and all(x.shape == xs[0].shape for x in xs)):
+        xs = [x.contiguous() for x in xs]
+        b, c, h, w = xs[0].shape
+        descs = (_native.MzHeadDesc * len(heads))(*[
+            _native.MzHeadDesc(conv.weight.data_ptr(), conv.bias.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
+                               fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), c, h * w, conv.out_channels,
+                               fc[0].out_features, fc[2].out_features) for conv, fc, _ in heads])
+        outs = [torch.empty((b, fc[2].out_features), dtype=torch.float32, device=xs[0].device) for _, fc, _ in heads]
+        x_ptrs = (ctypes.c_void_p * len(heads))(*[x.data_ptr() for x in xs])
+        pointers = (ctypes.c_void_p * len(heads))(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(xs[0].device):
+            rc = _native.load().mzmcts_conv_heads_multi(ctypes.addressof(x_ptrs), ctypes.addressof(descs), len(heads),
+                                                        ctypes.addressof(pointers), b,
+                                                        torch.cuda.current_stream(xs[0].device).cuda_stream)
+        if rc == 0:
+            return outs
+        if rc != -1:
+            raise RuntimeError(f"mzmcts_conv_heads_multi failed ({rc}) on tensors of shape {tuple(xs[0].shape)}")
+    return [fc(conv(x).reshape(-1, flat_size)) for x, (conv, fc, flat_size) in inputs_and_heads]
+
+
 def conv_head(x, conv, fc, flat_size):
     return conv_heads(x, [(conv, fc, flat_size)])[0]
 
@@ -806,10 +834,10 @@ class MuZeroResidualNetwork(AbstractNetwork):
         if fused is not None:
             raw, next_state, features = fused
             dyn, pred = self.dynamics_network.module, self.prediction_network.module
-            reward = conv_head(raw, dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward)
-            value, policy_logits = conv_heads(features, [
-                (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value),
-                (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy)])
+            reward, value, policy_logits = conv_heads_multi([
+                (raw, (dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward)),
+                (features, (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value)),
+                (features, (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy))])
             return value, reward, policy_logits, next_state
         next_state, reward = self.dynamics_from_planes(planes, out_state)
         policy_logits, value = self.prediction(next_state)
