@@ -77,3 +77,86 @@ def test_flat_weights_single_process_roundtrip():
     assert flat.broadcast() is None                      # no process group: a no-op
     model.set_weights({k: torch.zeros_like(v) for k, v in model.state_dict().items()})
     assert float(flat.flat.abs().sum()) == 0.0           # load_state_dict writes through the views
+
+
+def _loop_worker(rank, world, port, out_dir):
+    """One many-env actor per rank running ManyEnvLoop.continuous_self_play together (self_play.py:31-108 for E envs,
+    SURVEY.md section 8e): rank 0 alone talks to the shared storage; the loop condition and the weights travel by
+    broadcast.  The search itself is replaced by canned games (no GPU here)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    actor_mod = importlib.import_module("muzero-hypermodel_amd.actor")
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    ttt = importlib.import_module("muzero-hypermodel_amd.games.tictactoe")
+    actor_mod.init_distributed(backend="gloo")
+    config = ttt.MuZeroConfig()
+    config.training_steps, config.ratio, config.self_play_delay, config.temperature_threshold = 6, None, 0, None
+    torch.manual_seed(5 + rank)                          # ranks start with different weights
+    model = models.MuZeroNetwork(config)
+    model.eval()
+    log = []
+
+    class Storage:                                       # only rank 0 may touch it
+        info = {"training_step": 0, "terminate": False, "num_played_steps": 0}
+
+        def get_info(self, key):
+            assert rank == 0
+            log.append(key)
+            if key == "weights":
+                return {k: v + float(self.info["training_step"]) if v.dtype == torch.float32 else v
+                        for k, v in fresh.items()}
+            return self.info[key]
+
+    class Replay:
+        def __init__(self):
+            self.saved = []
+
+        def save_game(self, gh, shared_storage=None):
+            self.saved.append(gh.weights_version)
+            if rank == 0:
+                Storage.info["training_step"] += 1
+
+    fresh = {k: v.clone() for k, v in models.MuZeroNetwork(config).state_dict().items()}
+
+    class Actor(sp.ManyEnvLoop):
+        E = 2
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.config, self.model, self.passes = config, model, 0
+
+        def set_weights(self, w):
+            raise AssertionError("several ranks: weights arrive by broadcast")
+
+        def _play_pass(self, temperature, threshold, moves_per_pass):
+            assert moves_per_pass == 3
+            self.passes += 1
+            gh = sp.GameHistory()
+            gh.action_history, gh.reward_history, gh.root_values = [0, 1], [0, 1.0], [0.5]
+            return [(self.passes % 2, gh)]
+
+        def close(self):
+            pass
+    actor = Actor()
+    replay = Replay()
+    actor.continuous_self_play(Storage() if rank == 0 else None, replay, False, moves_per_pass=3)
+    flat = actor._loop_state()["flat"].flat
+    torch.save({"passes": actor.passes, "saved": replay.saved, "checksum": float(flat.double().sum()), "log": log},
+               os.path.join(out_dir, f"loop{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_many_env_loop_world2(tmp_path):
+    world = 2
+    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "loop0.pt")
+    r1 = torch.load(tmp_path / "loop1.pt")
+    assert r0["passes"] == r1["passes"] == 6             # both ranks made the same passes until training_steps = 6
+    assert r0["checksum"] == r1["checksum"]              # rank 1 holds rank 0's last pulled weights
+    assert r1["log"] == []                               # rank 1 never touched the storage
+    assert r0["log"].count("weights") == 6 and r0["log"][:3] == ["training_step", "terminate", "weights"]
+    assert [v[1] for v in r0["saved"]] == [0, 1, 2, 3, 4, 5] == [v[1] for v in r1["saved"]]   # weight versions agree
