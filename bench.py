@@ -52,7 +52,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_* / fp32 VALU peak (same guide); the residual nets run in fp32
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_* / fp32 VALU peak (same guide)
+F16_MATRIX_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide; the 2:1-sparsity figure is never used)
 # reference Python / oracle port, 1 thread, same inputs, measured in the build container (Xeon 2.1 GHz):
 # CartPole: C port 324e3 sims/s vs reference 1559 sims/s (tests/golden/g10_reference_speed.npz).  An extrapolation
 # to another CPU, kept only as a labelled side figure; `cpu_baseline.value` is the port itself.
@@ -619,16 +620,18 @@ def roofline_leg(wl, steps, device):
                          "achieved_GBs": per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else None,
                          "frac_of_hbm_peak": per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS if avg_us > 0 else None}
     if not wl.fused:
-        kernels["recurrent_inference"] = network_leg(wl, device)
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        kernels.update(network_leg(wl, device))
+    # the dominant KERNEL: the whole-call entry (several launches) is reported but is not a kernel
+    single = {k: v for k, v in kernels.items() if k != "recurrent_inference" or "board_tower" not in kernels}
+    dominant = max(single, key=lambda k: single[k]["avg_us"])
     d = kernels[dominant]
     if d["bound"] == "mfma":
         roofline = {"bound": "mfma", "kernel": d["what"], "achieved": d["achieved_TFLOPs"],
-                    "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": d["achieved_TFLOPs"] / FP32_MATRIX_PEAK_TFLOPS,
+                    "peak": d["peak_TFLOPs"], "unit": "TFLOP/s", "frac": d["frac_of_matrix_peak"],
                     "traffic": None, "avg_kernel_us": d["avg_us"], "flops_per_launch": d["flops_per_launch"],
-                    "dtype": "fp32 (parity bar 1e-5 keeps the residual networks in fp32; fp32 MFMA peak = fp32 VALU peak)",
-                    "timing": "torch.cuda.Event pairs on the launch stream around the launches of one recurrent "
-                              "inference of all envs, eager, mean over repeats",
+                    "precision": d.get("precision", "fp32"),
+                    "fp32_equivalent_TFLOPs": d.get("fp32_equivalent_TFLOPs"),
+                    "timing": "torch.cuda.Event pairs on the launch stream around the launch, eager, mean over repeats",
                     "mean_select_depth": mean_depth, "algorithmic_bytes_per_simulation": bytes_sim}
         return roofline, kernels
     kernel_name = f"mz::{dominant}_kernel"
@@ -658,32 +661,67 @@ def roofline_leg(wl, steps, device):
     return roofline, kernels
 
 
+def tower_conv_flops(config):
+    """FLOPs (2 per multiply-add) of the 3x3 convolutions of one recurrent inference of one sample: the dynamics stem
+    and the residual blocks of the dynamics and prediction networks -- what mzmcts_board_tower runs."""
+    _, h, w = config.observation_shape
+    if config.downsample:
+        h, w = math.ceil(h / 16), math.ceil(w / 16)
+    c, b = config.channels, config.blocks
+    return _conv_flops(c + 1, c, 3, h, w) + 4 * b * _conv_flops(c, c, 3, h, w)
+
+
+def _timed(call, device, repeats):
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize(device)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(repeats):
+        call()
+    stop.record()
+    torch.cuda.synchronize(device)
+    return 1e3 * start.elapsed_time(stop) / repeats
+
+
 def network_leg(wl, device, repeats=20):
-    """Mean duration of the launches of ONE recurrent inference for all envs (dynamics + prediction networks on the
-    gathered batch), eager, and its FLOPs vs the fp32 matrix peak."""
+    """The network side of one simulation for all envs, eager, torch events on the launch stream: the residual tower
+    kernel by itself (the dominant launch: every 3x3 convolution of the dynamics and prediction networks) and the whole
+    recurrent inference (tower + heads).  FLOPs vs the matrix peak of the path the tower runs on: exact fp32 MFMA for
+    16-channel networks; for 64-channel networks every fp32 product is three fp16 MFMA products (csrc/board_conv.hip),
+    so the executed FLOPs are 3 x the algorithmic ones and the peak is the dense f16 one."""
     engine, model = wl.engine, wl.model
-    flops = recurrent_inference_flops(wl.config) * engine.E
+    out = {}
     with torch.no_grad():
         if len(engine.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
             planes = engine.batch_planes                     # the dynamics input the last search's gather left behind
-            call = lambda: model.recurrent_inference_from_planes(planes, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
+            slab = engine.pool[1].view(engine.E, *engine.state_shape)
+            whole = lambda: model.recurrent_inference_from_planes(planes, out_state=slab)  # noqa: E731
+            if model._recurrent_tower(planes, slab) is not None:
+                split = wl.config.channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
+                us = _timed(lambda: model._recurrent_tower(planes, slab), device, repeats)
+                alg = tower_conv_flops(wl.config) * engine.E
+                executed = alg * (3 if split else 1)
+                peak = F16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
+                tf = executed / (us * 1e-6) / 1e12
+                out["board_tower"] = {
+                    "bound": "mfma", "what": "mz::board_tower_split_kernel" if split else "mz::board_tower_kernel",
+                    "avg_us": us, "launches": repeats, "flops_per_launch": executed, "algorithmic_flops_per_launch": alg,
+                    "achieved_TFLOPs": tf, "peak_TFLOPs": peak, "frac_of_matrix_peak": tf / peak,
+                    "precision": "two fp16 halves per operand, three products, fp32 accumulate" if split else "fp32 MFMA",
+                    "fp32_equivalent_TFLOPs": alg / (us * 1e-6) / 1e12}
         else:
             hidden = engine.batch_hidden.view(engine.E, *engine.state_shape)
-            call = lambda: model.recurrent_inference(hidden, engine.batch_action, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
-        for _ in range(3):
-            call()
-        torch.cuda.synchronize(device)
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(repeats):
-            call()
-        stop.record()
-        torch.cuda.synchronize(device)
-    avg_us = 1e3 * start.elapsed_time(stop) / repeats
-    tf = flops / (avg_us * 1e-6) / 1e12
-    return {"bound": "mfma", "what": "recurrent_inference (dynamics + prediction networks, all launches of one call)",
-            "avg_us": avg_us, "launches": repeats, "flops_per_launch": flops, "achieved_TFLOPs": tf,
-            "frac_of_fp32_matrix_peak": tf / FP32_MATRIX_PEAK_TFLOPS}
+            whole = lambda: model.recurrent_inference(hidden, engine.batch_action, out_state=engine.pool[1].view(engine.E, *engine.state_shape))  # noqa: E731
+        us = _timed(whole, device, repeats)
+    flops = recurrent_inference_flops(wl.config) * engine.E
+    out["recurrent_inference"] = {"bound": "mfma", "what": "recurrent_inference (tower + heads, all launches of one call)",
+                                  "avg_us": us, "launches": repeats, "flops_per_launch": flops,
+                                  "achieved_TFLOPs": flops / (us * 1e-6) / 1e12, "peak_TFLOPs": FP32_MATRIX_PEAK_TFLOPS,
+                                  "frac_of_matrix_peak": flops / (us * 1e-6) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                                  "note": "algorithmic fp32 FLOPs of the whole call against the fp32 peak; the tower kernel has "
+                                          "its own entry with the FLOPs it really executes"}
+    return out
 
 
 def pmc_traffic(kernel, envs):

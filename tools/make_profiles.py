@@ -23,7 +23,24 @@ copy("record_size_ceiling.jsonl", "record_size_ceiling.jsonl")
 copy("conv_bench.jsonl", "conv_bench.jsonl")
 copy("conv_pmc.json", "conv_pmc.json")
 copy("roofline_large_e.json", "roofline_large_e.json")
-copy("lockstep_pmc_large_e.json", "lockstep_pmc_large_e.json")
+if have("large_e_FETCH_SIZE.json") and have("large_e_WRITE_SIZE.json") and have("roofline_large_e.json"):
+    roof = json.load(open(os.path.join(G, "roofline_large_e.json")))
+    out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python3 tools/roofline_large_e.py 20 (separate "
+                      "passes: tools/profile_r02.sh large)", "unit": "MB per launch (raw counters, uncorrected)", "kernels": {}}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = json.load(open(os.path.join(G, f"large_e_{c}.json")))
+        for k, v in d["kernels"].items():
+            for short in ("select", "expand_backup"):
+                if f"mz::{short}_kernel" in k:
+                    out["kernels"].setdefault(short, {})[c + "_MB"] = v[c] / v["launches"] / 1024.0
+    for short, e in out["kernels"].items():
+        alg = roof["kernels"][short]["algorithmic_bytes_per_launch"] / 1e6
+        e["algorithmic_MB"] = alg
+        e["traffic_over_algorithmic"] = (e.get("FETCH_SIZE_MB", 0) * 1.048576 + e.get("WRITE_SIZE_MB", 0) * 1.048576) / alg
+        e["avg_us"] = roof["kernels"][short]["avg_us"]
+        e["frac_of_8TBs"] = roof["kernels"][short]["frac_of_8TBs"]
+    json.dump(out, open(os.path.join(P, f"{tag}_lockstep_pmc_large_e.json"), "w"), indent=1)
+    print("   lockstep_pmc_large_e.json")
 copy("connect4_mfma_pmc.json", "connect4_mfma_pmc.json")
 
 # SQ-counter picture of the fused kernel: the two passes (instruction counts; waits / activity) merged per kernel

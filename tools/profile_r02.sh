@@ -50,6 +50,26 @@ mfma)
         $PY "$R/bench.py" --workload connect4 --steps 1 --warmup 1 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 --no-graph > "$R/gpurun_out/mfma_run.log" 2>&1
     $PY "$R/tools/pmc_summary.py" /tmp/mfma_c4 --mfma --top 8 --tail 0.5 > "$R/gpurun_out/connect4_mfma_pmc.json"
     ;;
+large)
+    # lock-step tree kernels at HBM scale (2^20 trees): per-kernel time, then FETCH_SIZE / WRITE_SIZE in their own passes
+    cd "$R"
+    timeout -k 10 500 $PY tools/roofline_large_e.py 20 > gpurun_out/roofline_large_e.log 2>&1
+    tail -1 gpurun_out/roofline_large_e.log > gpurun_out/roofline_large_e.json
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace -d /tmp/le_$c -o t --output-format csv -- \
+            $PY "$R/tools/roofline_large_e.py" 20 > "$R/gpurun_out/le_$c.log" 2>&1
+        $PY "$R/tools/pmc_summary.py" /tmp/le_$c --top 3 > "$R/gpurun_out/large_e_$c.json"
+    done
+    ;;
+conv)
+    cd "$R"
+    $PY tools/conv_bench.py > gpurun_out/conv_bench.jsonl 2> gpurun_out/conv_bench.err
+    tools/_bin/record_size_ceiling 8 > gpurun_out/record_size_ceiling.jsonl
+    ;;
+all)
+    for part in bench4 stats mfma fusedsq traffic large conv; do bash "$R/tools/profile_r02.sh" $part || exit 1; done
+    ;;
 traffic)
     cd /tmp && export TMPDIR=/tmp
     for c in FETCH_SIZE WRITE_SIZE; do
