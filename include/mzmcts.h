@@ -92,6 +92,8 @@ typedef struct mzmcts_profile {
     int64_t select_depth_sum;  /* sum over launches and trees of the select depth (d-bar); move batches add
                                 * to it only while profiling is on (mzmcts_set_profiling) */
     int64_t simulations;       /* tree-simulations executed (launches x active trees)     */
+    double step_ms;            /* mzmcts_expand_backup_select launches (expand_backup + next select in one)  */
+    int64_t step_launches;
 } mzmcts_profile;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -158,6 +160,20 @@ int mzmcts_expand_backup(mzmcts_engine *engine, const float *value_logits, const
 /* Injected mode: already-decoded scalars (value, reward dev f64[E]; priors dev f64[E,A]). */
 int mzmcts_expand_backup_injected(mzmcts_engine *engine, const double *value, const double *reward,
                                   const double *priors, void *stream);
+
+/* One step of the lock-step loop in ONE launch: expand_backup of the simulation in flight followed by select of the
+ * next one (self_play.py:344-356, 407-431, then 321-343 of the next iteration) -- most of the nodes a descent visits
+ * were just rewritten by the backup and are still in the XCD's L2, and a launch boundary goes.  Arguments as
+ * mzmcts_expand_backup + mzmcts_select (/ mzmcts_select_planes / the injected form); not for the last simulation of a
+ * search (use mzmcts_expand_backup there).  Results are bit-identical to the two separate calls. */
+int mzmcts_expand_backup_select(mzmcts_engine *engine, const float *value_logits, const float *reward_logits,
+                                const float *policy_logits, const float *next_hidden, float *parent_hidden_out,
+                                int64_t *action_out, void *stream);
+int mzmcts_expand_backup_select_planes(mzmcts_engine *engine, const float *value_logits, const float *reward_logits,
+                                       const float *policy_logits, const float *next_hidden, float *planes_out,
+                                       int64_t *action_out, int32_t plane, int32_t action_space, void *stream);
+int mzmcts_expand_backup_select_injected(mzmcts_engine *engine, const double *value, const double *reward,
+                                         const double *priors, float *parent_hidden_out, int64_t *action_out, void *stream);
 
 /* Hidden-state pool: slab k (dev f32[E,H]) holds the state of the node expanded by simulation k-1
  * (slab 0 = roots).  mzmcts_next_slab() is the slab the coming expand_backup will own. */

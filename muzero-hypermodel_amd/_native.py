@@ -44,7 +44,8 @@ class MzProfile(ctypes.Structure):
                 ("root_ms", ctypes.c_double), ("fused_ms", ctypes.c_double),
                 ("select_launches", ctypes.c_int64), ("expand_backup_launches", ctypes.c_int64),
                 ("root_launches", ctypes.c_int64), ("fused_launches", ctypes.c_int64),
-                ("select_depth_sum", ctypes.c_int64), ("simulations", ctypes.c_int64)]
+                ("select_depth_sum", ctypes.c_int64), ("simulations", ctypes.c_int64),
+                ("step_ms", ctypes.c_double), ("step_launches", ctypes.c_int64)]
 
 
 class MzFcDesc(ctypes.Structure):
@@ -107,6 +108,9 @@ PROTOTYPES = {
     "mzmcts_conv_heads_multi": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, c_void, ctypes.c_int64, c_void]),
     "mzmcts_conv_head": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int64, c_void]),
     "mzmcts_unit_rescale": (ctypes.c_int, [c_void, c_void, ctypes.c_int64, ctypes.c_int32, c_void]),
+    "mzmcts_expand_backup_select": (ctypes.c_int, [c_void] * 8),
+    "mzmcts_expand_backup_select_planes": (ctypes.c_int, [c_void] * 7 + [ctypes.c_int32, ctypes.c_int32, c_void]),
+    "mzmcts_expand_backup_select_injected": (ctypes.c_int, [c_void] * 7),
     "mzmcts_board_conv_packed_floats": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_board_conv_pack": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),

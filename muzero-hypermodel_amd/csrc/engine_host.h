@@ -63,6 +63,10 @@ hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value
                                 const float* policy_logits, const double* inj_value, const double* inj_reward,
                                 const double* inj_priors, bool injected, hipStream_t stream,
                                 const LaunchTiming* timing);
+hipError_t launch_expand_backup_select(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
+                                       const float* policy_logits, const double* inj_value, const double* inj_reward,
+                                       const double* inj_priors, bool injected, float* hidden_out, int64_t* action_out,
+                                       hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t stream);
 hipError_t launch_seed_streams(uint32_t* keys, int32_t* pos, const uint32_t* seeds, int E, hipStream_t stream);
 }  // namespace mz
@@ -76,7 +80,7 @@ hipError_t read_stamp_sums_narrow(unsigned long long* out, bool reset);
 
 inline thread_local std::string g_create_error;
 
-enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfFused = 3 };
+enum ProfKind { kProfSelect = 0, kProfBackup = 1, kProfRoot = 2, kProfFused = 3, kProfStep = 4 };
 constexpr size_t kLdsPerWorkgroup = 160 * 1024;  // gfx950
 struct EventPair {
     hipEvent_t begin, end;

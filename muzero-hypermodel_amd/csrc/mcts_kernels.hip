@@ -46,30 +46,11 @@ __device__ __forceinline__ void stage_pbc_table(double* table, const TreeParams&
 // select: descend every tree from its root to a leaf (self_play.py:321-335, 364-379) and gather the
 // parent hidden state + action of the leaf into the inference batch (self_play.py:339-343).
 // -------------------------------------------------------------------------------------------------
+// The descent of tree e for simulation `sim` (pbc_table staged; group-uniform control flow).
 template <int G, int CH, bool FUSE_GATHER>
-__global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim, float* __restrict__ hidden_out,
-                                                          int64_t* __restrict__ action_out) {
-    extern __shared__ double pbc_table[];  // [2][S+1]
-    constexpr int kTrees = kThreads / G;
-    const int e = blockIdx.x * kTrees + threadIdx.x / G;
-    const int j = threadIdx.x % G;
-    const int group_base = threadIdx.x - j;  // lane of the group leader inside the wave
-    // Per-tree control words first, the table after: at HBM scale every dependent round trip to memory costs
-    // microseconds, so the tree's own loads go out before the (cache-resident) table is staged, and the root
-    // block is touched now so that the descent's first record is on its way while the table lands in LDS.
-    const bool in_range = e < p.E;
-    int n_root = 0;
-    MinMax mm{};
-    int32_t mt_pos = 0;
-    if (in_range) {
-        n_root = p.root_children[e];
-        mm = p.min_max[e];
-        if (j == 0) mt_pos = p.mt_pos[e];
-        (void)*reinterpret_cast<const volatile int32_t*>(p.blocks + static_cast<size_t>(e) * p.line_stride + (16u * j) % p.block_stride);
-    }
-    stage_pbc_table(pbc_table, p);
-    __syncthreads();
-    if (!in_range) return;
+__device__ __forceinline__ void select_tree(const TreeParams& p, int sim, const double* pbc_table, int e, int j, int group_base,
+                                            int n_root, const MinMax& mm, int32_t mt_pos, float* __restrict__ hidden_out,
+                                            int64_t* __restrict__ action_out) {
     if (n_root == 0) {  // inactive tree: keep the batch row defined
         if (j == 0) {
             p.path_len[e] = 0;
@@ -113,6 +94,34 @@ __global__ __launch_bounds__(kThreads) void select_kernel(TreeParams p, int sim,
             for (int i = j; i < p.H; i += G) dst[i] = src[i];
         }
     }
+}
+
+// (8 waves per SIMD: a descent is a chain of dependent loads, the trees in flight are what hides their latency)
+template <int G, int CH, bool FUSE_GATHER>
+__global__ __launch_bounds__(kThreads, 8) void select_kernel(TreeParams p, int sim, float* __restrict__ hidden_out,
+                                                          int64_t* __restrict__ action_out) {
+    extern __shared__ double pbc_table[];  // [2][S+1]
+    constexpr int kTrees = kThreads / G;
+    const int e = blockIdx.x * kTrees + threadIdx.x / G;
+    const int j = threadIdx.x % G;
+    const int group_base = threadIdx.x - j;  // lane of the group leader inside the wave
+    // Per-tree control words first, the table after: at HBM scale every dependent round trip to memory costs
+    // microseconds, so the tree's own loads go out before the (cache-resident) table is staged, and the root
+    // block is touched now so that the descent's first record is on its way while the table lands in LDS.
+    const bool in_range = e < p.E;
+    int n_root = 0;
+    MinMax mm{};
+    int32_t mt_pos = 0;
+    if (in_range) {
+        n_root = p.root_children[e];
+        mm = p.min_max[e];
+        if (j == 0) mt_pos = p.mt_pos[e];
+        (void)*reinterpret_cast<const volatile int32_t*>(p.blocks + static_cast<size_t>(e) * p.line_stride + (16u * j) % p.block_stride);
+    }
+    stage_pbc_table(pbc_table, p);
+    __syncthreads();
+    if (!in_range) return;
+    select_tree<G, CH, FUSE_GATHER>(p, sim, pbc_table, e, j, group_base, n_root, mm, mt_pos, hidden_out, action_out);
 }
 
 // Stand-alone gather for large hidden states (ResNet planes): one workgroup row per tree,
@@ -224,22 +233,15 @@ __global__ __launch_bounds__(kThreads) void expand_roots_kernel(TreeParams p, co
 // expand_backup: decode value/reward, expand the leaf over the full action space, back the value
 // up the search path with min-max statistics (self_play.py:344-356, 407-431, 452-466, 560-562).
 // -------------------------------------------------------------------------------------------------
+// expand + backup of tree e for simulation `sim`; returns (in every lane of the group) the min-max statistics it leaves.
 template <int G, int CH, bool INJECTED>
-__global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, int sim,
-                                                                 const float* __restrict__ value_logits,
-                                                                 const float* __restrict__ reward_logits,
-                                                                 const float* __restrict__ policy_logits,
-                                                                 const double* __restrict__ inj_value,
-                                                                 const double* __restrict__ inj_reward,
-                                                                 const double* __restrict__ inj_priors) {
-    constexpr int kTrees = kThreads / G;
-    __shared__ StagedNode staged[kTrees][kStageLevels];
-
-    const int tree_in_block = threadIdx.x / G;
-    const int e = blockIdx.x * kTrees + tree_in_block;
-    const int j = threadIdx.x % G;
-    if (e >= p.E) return;
-    if (p.root_children[e] == 0) return;
+__device__ __forceinline__ MinMax expand_backup_tree(const TreeParams& p, int sim, int e, int j, StagedNode* staged,
+                                                     const float* __restrict__ value_logits,
+                                                     const float* __restrict__ reward_logits,
+                                                     const float* __restrict__ policy_logits,
+                                                     const double* __restrict__ inj_value,
+                                                     const double* __restrict__ inj_reward,
+                                                     const double* __restrict__ inj_priors) {
     const int depth = p.path_len[e];  // >= 1
 
     double value;
@@ -278,14 +280,74 @@ __global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, i
     MinMax mm = p.min_max[e];
     double root_value_sum = (j == 0) ? p.root_value_sum[e] : 0.0;
     const double root_reward = (j == 0) ? p.root_reward[e] : 0.0;
-    backup<G>(tree, depth, sim, value, reward_f, p.P == 2, p.discount, mm, root_value_sum, root_reward,
-              staged[tree_in_block], j, loc_new);
+    backup<G>(tree, depth, sim, value, reward_f, p.P == 2, p.discount, mm, root_value_sum, root_reward, staged, j, loc_new);
     if (j == 0) {
         p.root_value_sum[e] = root_value_sum;
         p.min_max[e] = mm;
         if (depth > p.max_depth[e]) p.max_depth[e] = depth;
         p.depth_sum[e] += depth;
     }
+    mm.minimum = __shfl(mm.minimum, 0, G);               // the leader owns the running statistics
+    mm.maximum = __shfl(mm.maximum, 0, G);
+    return mm;
+}
+
+template <int G, int CH, bool INJECTED>
+__global__ __launch_bounds__(kThreads) void expand_backup_kernel(TreeParams p, int sim,
+                                                                 const float* __restrict__ value_logits,
+                                                                 const float* __restrict__ reward_logits,
+                                                                 const float* __restrict__ policy_logits,
+                                                                 const double* __restrict__ inj_value,
+                                                                 const double* __restrict__ inj_reward,
+                                                                 const double* __restrict__ inj_priors) {
+    constexpr int kTrees = kThreads / G;
+    __shared__ StagedNode staged[kTrees][kStageLevels];
+    const int tree_in_block = threadIdx.x / G;
+    const int e = blockIdx.x * kTrees + tree_in_block;
+    const int j = threadIdx.x % G;
+    if (e >= p.E) return;
+    if (p.root_children[e] == 0) return;
+    (void)expand_backup_tree<G, CH, INJECTED>(p, sim, e, j, staged[tree_in_block], value_logits, reward_logits, policy_logits,
+                                              inj_value, inj_reward, inj_priors);
+}
+
+// -------------------------------------------------------------------------------------------------
+// One step of the lock-step loop in ONE launch: expand + backup of simulation `sim`, then the descent of simulation
+// sim + 1 for the same trees.  63 % of the nodes a descent visits lie on the path the backup has just rewritten (CartPole
+// traces): in one launch they are served by the XCD's L2 instead of a second trip to HBM, and a launch boundary goes.
+// -------------------------------------------------------------------------------------------------
+template <int G, int CH, bool INJECTED, bool FUSE_GATHER>
+__global__ __launch_bounds__(kThreads) void expand_backup_select_kernel(TreeParams p, int sim,
+                                                                        const float* __restrict__ value_logits,
+                                                                        const float* __restrict__ reward_logits,
+                                                                        const float* __restrict__ policy_logits,
+                                                                        const double* __restrict__ inj_value,
+                                                                        const double* __restrict__ inj_reward,
+                                                                        const double* __restrict__ inj_priors,
+                                                                        float* __restrict__ hidden_out,
+                                                                        int64_t* __restrict__ action_out) {
+    extern __shared__ double pbc_table[];  // [2][S+1]
+    constexpr int kTrees = kThreads / G;
+    __shared__ StagedNode staged[kTrees][kStageLevels];
+    const int tree_in_block = threadIdx.x / G;
+    const int e = blockIdx.x * kTrees + tree_in_block;
+    const int j = threadIdx.x % G;
+    const int group_base = threadIdx.x - j;
+    stage_pbc_table(pbc_table, p);
+    __syncthreads();
+    if (e >= p.E) return;
+    const int n_root = p.root_children[e];
+    MinMax mm{};
+    if (n_root != 0)
+        mm = expand_backup_tree<G, CH, INJECTED>(p, sim, e, j, staged[tree_in_block], value_logits, reward_logits,
+                                                 policy_logits, inj_value, inj_reward, inj_priors);
+    // The descent reads records that lanes of THIS wavefront have just stored (a tree belongs to one lane group): the
+    // wavefront's vector-memory operations reach its CU's L1 in program order, so ordering them inside the wavefront is
+    // enough -- no other CU touches these records during the launch, and lines cached by earlier launches were dropped
+    // at the launch boundary.
+    group_memory_fence();
+    const int32_t mt_pos = (j == 0) ? p.mt_pos[e] : 0;
+    select_tree<G, CH, FUSE_GATHER>(p, sim + 1, pbc_table, e, j, group_base, n_root, mm, mt_pos, hidden_out, action_out);
 }
 
 // numpy.random.seed(seeds[e]) for every stream, on the device copy.
@@ -656,6 +718,39 @@ hipError_t launch_expand_backup(const TreeParams& p, int sim, const float* value
                           value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors);
     });
     return hipGetLastError();
+}
+
+// expand_backup(sim) + select(sim + 1) in one launch; the caller still runs the stand-alone gather for large hidden states
+hipError_t launch_expand_backup_select(const TreeParams& p, int sim, const float* value_logits, const float* reward_logits,
+                                       const float* policy_logits, const double* inj_value, const double* inj_reward,
+                                       const double* inj_priors, bool injected, float* hidden_out, int64_t* action_out,
+                                       hipStream_t stream, const LaunchTiming* timing) {
+    const size_t lds = sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1);
+    const int grid = tree_grid(p);
+    const bool fuse = p.H <= kFuseGatherMaxFloats;
+    dispatch_group(p, [&](auto g, auto ch) {
+        constexpr int G = decltype(g)::value;
+        constexpr int CH = decltype(ch)::value;
+#define MZ_STEP(INJ, FG)                                                                                                  \
+    launch_kernel(expand_backup_select_kernel<G, CH, INJ, FG>, dim3(grid), dim3(kThreads), lds, stream, timing, p, sim,    \
+                  value_logits, reward_logits, policy_logits, inj_value, inj_reward, inj_priors, hidden_out, action_out)
+        if (injected) {
+            if (fuse) MZ_STEP(true, true); else MZ_STEP(true, false);
+        } else {
+            if (fuse) MZ_STEP(false, true); else MZ_STEP(false, false);
+        }
+#undef MZ_STEP
+    });
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    if (!fuse && hidden_out) {
+        const int per_row = (p.H + 3) / 4;
+        int gy = (per_row + 255) / 256;
+        if (gy > 8) gy = 8;
+        gather_hidden_kernel<<<dim3(p.E, gy), dim3(256), 0, stream>>>(p, hidden_out);
+        err = hipGetLastError();
+    }
+    return err;
 }
 
 hipError_t launch_copy_slab(const float* src, float* dst, size_t n, hipStream_t stream) {

@@ -389,6 +389,59 @@ int mzmcts_expand_backup_injected(mzmcts_engine* eng, const double* value, const
     return MZMCTS_OK;
 }
 
+// expand_backup of the simulation in flight + select of the next one, one launch (mcts_kernels.hip)
+static int step_common(mzmcts_engine* eng, const float* value_logits, const float* reward_logits, const float* policy_logits,
+                       const float* next_hidden, const double* inj_value, const double* inj_reward, const double* inj_priors,
+                       bool injected, float* parent_hidden_out, int64_t* action_out, hipStream_t stream, const char* who) {
+    if (!eng->roots_ready || eng->sim >= eng->p.S) return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": no simulation in flight");
+    if (eng->sim + 1 >= eng->p.S)
+        return fail(eng, MZMCTS_ERR_INVALID, std::string(who) + ": this is the search's last simulation (use mzmcts_expand_backup)");
+    if (next_hidden && eng->p.H > 0) {
+        float* slab = eng->p.hidden + (static_cast<size_t>(eng->sim) + 1) * eng->p.E * eng->p.H;
+        MZ_HIP(eng, mz::launch_copy_slab(next_hidden, slab, static_cast<size_t>(eng->p.E) * eng->p.H, stream));
+    }
+    {
+        ProfScope scope(eng, stream, kProfStep);
+        MZ_HIP(eng, mz::launch_expand_backup_select(eng->p, eng->sim, value_logits, reward_logits, policy_logits, inj_value,
+                                                    inj_reward, inj_priors, injected,
+                                                    eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream, scope.get()));
+    }
+    eng->sim += 1;
+    return MZMCTS_OK;
+}
+
+int mzmcts_expand_backup_select(mzmcts_engine* eng, const float* value_logits, const float* reward_logits,
+                                const float* policy_logits, const float* next_hidden, float* parent_hidden_out,
+                                int64_t* action_out, void* stream_) {
+    if (!eng || !value_logits || !reward_logits || !policy_logits)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_select: null argument");
+    return step_common(eng, value_logits, reward_logits, policy_logits, next_hidden, nullptr, nullptr, nullptr, false,
+                       parent_hidden_out, action_out, static_cast<hipStream_t>(stream_), "mzmcts_expand_backup_select");
+}
+
+int mzmcts_expand_backup_select_planes(mzmcts_engine* eng, const float* value_logits, const float* reward_logits,
+                                       const float* policy_logits, const float* next_hidden, float* planes_out,
+                                       int64_t* action_out, int32_t plane, int32_t action_space, void* stream_) {
+    if (!eng || !value_logits || !reward_logits || !policy_logits || !planes_out || !action_out)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_select_planes: null argument");
+    if (plane <= 0 || action_space <= 0 || eng->p.H <= 0 || eng->p.H % plane != 0)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_select_planes: hidden_floats must be channels x plane");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = step_common(eng, value_logits, reward_logits, policy_logits, next_hidden, nullptr, nullptr, nullptr, false, nullptr,
+                         action_out, stream, "mzmcts_expand_backup_select_planes");
+    if (rc) return rc;
+    MZ_HIP(eng, mz::launch_gather_dynamics_input(eng->p, action_out, planes_out, plane, action_space, stream));
+    return MZMCTS_OK;
+}
+
+int mzmcts_expand_backup_select_injected(mzmcts_engine* eng, const double* value, const double* reward, const double* priors,
+                                         float* parent_hidden_out, int64_t* action_out, void* stream_) {
+    if (!eng || !value || !reward || !priors)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_expand_backup_select_injected: null argument");
+    return step_common(eng, nullptr, nullptr, nullptr, nullptr, value, reward, priors, true, parent_hidden_out, action_out,
+                       static_cast<hipStream_t>(stream_), "mzmcts_expand_backup_select_injected");
+}
+
 float* mzmcts_hidden_slab(mzmcts_engine* eng, int32_t slab) {
     if (!eng || slab < 0 || slab > eng->p.S || eng->p.H == 0) return nullptr;
     return eng->p.hidden + static_cast<size_t>(slab) * eng->p.E * eng->p.H;
@@ -901,6 +954,10 @@ int mzmcts_get_profile(mzmcts_engine* eng, mzmcts_profile* out, int32_t reset) {
             case kProfBackup:
                 eng->prof.expand_backup_ms += ms;
                 eng->prof.expand_backup_launches += 1;
+                break;
+            case kProfStep:
+                eng->prof.step_ms += ms;
+                eng->prof.step_launches += 1;
                 break;
             case kProfFused:
                 eng->prof.fused_ms += ms;

@@ -520,20 +520,20 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
                 packed_u[u] = (i < count) ? acc.path_load(hi - i) : 0;
             }
             double vs_u[kPer];
-            ChildLinks lk_u[kPer];
+            float2 rv_u[kPer];                           // {reward, visits}: the first 8 bytes of the child's ChildLinks
 #pragma unroll
             for (int u = 0; u < kPer; ++u) {
                 const int i = j + u * G;
                 if (i < count) {
                     const int slot = packed_u[u] & 0xff;
                     vs_u[u] = (acc.stats(packed_u[u] >> 8) + slot)->value_sum;
-                    lk_u[u] = *(acc.links(packed_u[u] >> 8) + slot);
+                    rv_u[u] = *reinterpret_cast<const float2*>(acc.links(packed_u[u] >> 8) + slot);
                 }
             }
 #pragma unroll
             for (int u = 0; u < kPer; ++u) {
                 const int i = j + u * G;
-                if (i < count) staged[i] = StagedNode{vs_u[u], lk_u[u].reward, lk_u[u].visits};
+                if (i < count) staged[i] = StagedNode{vs_u[u], rv_u[u].x, __builtin_bit_cast(int32_t, rv_u[u].y)};
             }
             group_memory_fence();
             if (j == 0) {

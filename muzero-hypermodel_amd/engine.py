@@ -71,6 +71,9 @@ class BatchedMCTS:
         self._batch_keep = []
         self._fc_flat = None
         self.fused_hidden_in_lds = True
+        # lock-step loop: expand_backup + next select in one launch (mzmcts_expand_backup_select).  Bit-identical and one
+        # launch fewer per simulation, but not faster where measured: off by default
+        self.fused_step = False
 
         with torch.cuda.device(self.device):
             self.pool = torch.empty((self.S + 1, self.E, self.H), dtype=torch.float32, device=self.device)
@@ -228,6 +231,34 @@ class BatchedMCTS:
         self._check(self._lib.mzmcts_expand_backup_injected(self._h, v.data_ptr(), r.data_ptr(),
                                                             p.data_ptr(), self._stream()))
 
+    # expand_backup of the simulation in flight + select of the next one in ONE launch (not for the last simulation)
+    def expand_backup_select(self, value_logits, reward_logits, policy_logits, next_hidden=None, gather=True):
+        v, r, p = self._f32(value_logits, self.F), self._f32(reward_logits, self.F), self._f32(policy_logits, self.A)
+        h = None if next_hidden is None else self._f32(next_hidden.reshape(self.E, -1), self.H)
+        self._keep = (v, r, p, h)
+        self._check(self._lib.mzmcts_expand_backup_select(
+            self._h, v.data_ptr(), r.data_ptr(), p.data_ptr(), None if h is None else h.data_ptr(),
+            self.batch_hidden.data_ptr() if gather and self.H else None, self.batch_action.data_ptr(), self._stream()))
+
+    def expand_backup_select_planes(self, value_logits, reward_logits, policy_logits):
+        v, r, p = self._f32(value_logits, self.F), self._f32(reward_logits, self.F), self._f32(policy_logits, self.A)
+        c, h, w = self.state_shape
+        self._keep = (v, r, p)
+        self._check(self._lib.mzmcts_expand_backup_select_planes(
+            self._h, v.data_ptr(), r.data_ptr(), p.data_ptr(), None, self.batch_planes.data_ptr(),
+            self.batch_action.data_ptr(), h * w, self.A, self._stream()))
+        return self.batch_planes
+
+    def expand_backup_select_injected(self, value, reward, priors, gather=False):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float64), device=self.device).contiguous()
+        r = torch.as_tensor(np.asarray(reward, dtype=np.float64), device=self.device).contiguous()
+        p = torch.as_tensor(np.asarray(priors, dtype=np.float64), device=self.device).contiguous()
+        assert v.shape == (self.E,) and r.shape == (self.E,) and p.shape == (self.E, self.A)
+        self._keep = (v, r, p)
+        self._check(self._lib.mzmcts_expand_backup_select_injected(
+            self._h, v.data_ptr(), r.data_ptr(), p.data_ptr(), self.batch_hidden.data_ptr() if gather and self.H else None,
+            self.batch_action.data_ptr(), self._stream()))
+
     def _f32(self, t, width):
         assert t.is_cuda and t.dtype == torch.float32, "network outputs must be fp32 device tensors"
         t = t.contiguous()
@@ -264,16 +295,45 @@ class BatchedMCTS:
         return {k: v.reshape(self.S + 1, self.A) for k, v in out.items()}
 
     # ---- the simulation loop ---------------------------------------------------------------------
-    def _simulate_once(self, model):
-        slab = self.next_slab()
-        if len(self.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
-            # residual networks: the gather writes the dynamics input itself (state planes + action plane)
-            value, reward, policy, _ = model.recurrent_inference_from_planes(self.select_planes(), out_state=slab)
+    def _planes_path(self, model):
+        return len(self.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes")
+
+    def _select_for(self, model):
+        """The descent of the simulation about to run (its gather feeds the network)."""
+        if self._planes_path(model):
+            self.select_planes()     # residual networks: the gather writes the dynamics input (state planes + action plane)
         else:
             self.select()
-            value, reward, policy, _ = model.recurrent_inference(
-                self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)
+
+    def _infer(self, model):
+        slab = self.next_slab()
+        if self._planes_path(model):
+            return model.recurrent_inference_from_planes(self.batch_planes, out_state=slab)
+        return model.recurrent_inference(self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)
+
+    def _simulate_once(self, model):
+        """One simulation as three steps (select, inference, expand_backup): what the parity tests drive."""
+        self._select_for(model)
+        value, reward, policy, _ = self._infer(model)
         self.expand_backup(value, reward, policy, None)
+
+    def _simulate_all(self, model):
+        """The S simulations of a search: select once, then per simulation the inference and ONE tree launch -- expand +
+        backup of this simulation fused with the descent of the next (include/mzmcts.h mzmcts_expand_backup_select) --
+        and a plain expand_backup for the last."""
+        done = self.simulations_done()
+        self._select_for(model)
+        for s in range(done, self.S):
+            value, reward, policy, _ = self._infer(model)
+            if s + 1 < self.S and self.fused_step:
+                if self._planes_path(model):
+                    self.expand_backup_select_planes(value, reward, policy)
+                else:
+                    self.expand_backup_select(value, reward, policy, None)
+            else:
+                self.expand_backup(value, reward, policy, None)
+                if s + 1 < self.S:
+                    self._select_for(model)
 
     def _run_simulations(self, model):
         graph_ok = self.use_graph and not self._profiling
@@ -287,15 +347,13 @@ class BatchedMCTS:
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(graph):
-                for _ in range(self.S):
-                    self._simulate_once(model)
+                self._simulate_all(model)
             self._graph, self._graph_model = graph, model
             self._check(self._lib.mzmcts_set_simulations_done(self._h, 0))
             graph.replay()
             self._check(self._lib.mzmcts_set_simulations_done(self._h, self.S))
             return
-        for _ in range(self.S):
-            self._simulate_once(model)
+        self._simulate_all(model)
         self._eager_searches += 1
 
     # ---- fully-connected networks in-kernel ---------------------------------------------------------

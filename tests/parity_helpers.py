@@ -159,7 +159,7 @@ def _result_arrays(T, A, S):
 
 
 def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="cuda", temperature=1.0,
-                           record_paths=True, repeat=1, engine=None, group_width=0):
+                           record_paths=True, repeat=1, engine=None, group_width=0, fused_step=False):
     """Drive the HIP engine through the C ABI with injected streams.
 
     `repeat` tiles the T trees `repeat` times (env e replays stream e % T), which exercises batching:
@@ -190,13 +190,17 @@ def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="
     out = _result_arrays(E, A, S)
     value, reward, priors = tile(streams["value"]), tile(streams["reward"]), tile(streams["priors"])
     for s in range(S):
-        engine.select(gather=False)
+        if s == 0 or not fused_step:
+            engine.select(gather=False)
         if record_paths:
             depth, actions, ties = engine.last_paths(with_ties=True)
             out["sim_depth"][:, s] = depth
             out["sim_actions"][:, s, :] = actions
             out["sim_ties"][:, s, :] = ties
-        engine.expand_backup_injected(value[:, s], reward[:, s], priors[:, s, :])
+        if fused_step and s + 1 < S:     # expand_backup(s) + select(s + 1) in one launch
+            engine.expand_backup_select_injected(value[:, s], reward[:, s], priors[:, s, :])
+        else:
+            engine.expand_backup_injected(value[:, s], reward[:, s], priors[:, s, :])
     st = engine.readout()
     out["noise"][:] = noise
     for key in ("visits", "child_value_sum", "child_prior", "child_reward", "root_value_sum", "root_visits",

@@ -75,6 +75,24 @@ def test_injected_traces_bit_exact_vs_reference_and_oracle(eng, oracle, name):
     assert np.array_equal(got["depth_sum"], fx["sim_depth"].sum(axis=1))
 
 
+@pytest.mark.parametrize("name", TRACE_FILES)
+def test_injected_traces_fused_step(eng, oracle, name):
+    """mzmcts_expand_backup_select (expand + backup of a simulation and the descent of the next in one launch): the same
+    bits as the three-step loop and the reference's traces, paths and tie lists included."""
+    fx = load_golden(name)
+    idx = list(range(len(fx["seed"])))
+    temps = fx["temperature"].tolist()
+    got = run_injected_on_engine(eng, None, fx, idx, temperature=temps, fused_step=True)
+    want = run_injected_on_oracle(oracle, fx, idx=idx, temperature=temps)
+    assert_exact(got, want, where=f"{name} (fused step) vs oracle: ")
+    S = int(fx["cfg_S"])
+    for key in ("noise", "visits", "child_value_sum", "child_prior", "child_reward"):
+        assert np.array_equal(got[key], fx[key]), key
+    assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, :S])
+    assert np.array_equal(got["sim_ties"], fx["sim_ties"][:, :, :S])
+    assert np.array_equal(got["depth_sum"], fx["sim_depth"].sum(axis=1))
+
+
 @pytest.mark.parametrize("name", ["g4_cartpole_traces", "g5_cartpole_ties_traces"])
 def test_injected_traces_one_lane_per_tree(eng, oracle, name):
     """group_width = 1 (two-action games): one lane owns a tree and loops over its children -- twice the trees per

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from parity_helpers import make_search_config
 
+STEP = "--fused-step" in sys.argv                     # expand_backup + next select in one launch
+sys.argv = [a for a in sys.argv if a != "--fused-step"]
 log2e = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 A = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 50
@@ -35,8 +37,13 @@ def move():
     engine.begin_search(legal, tp, True, num_legal=nl)
     engine._check(lib.mzmcts_expand_roots_injected(h, root_reward.data_ptr(), priors.data_ptr(), engine._stream()))
     for s in range(S):
-        engine.select(gather=True)
-        engine._check(lib.mzmcts_expand_backup_injected(h, value.data_ptr(), reward.data_ptr(), priors.data_ptr(), engine._stream()))
+        if s == 0 or not STEP:
+            engine.select(gather=True)
+        if STEP and s + 1 < S:
+            engine._check(lib.mzmcts_expand_backup_select_injected(h, value.data_ptr(), reward.data_ptr(), priors.data_ptr(),
+                                                                   engine.batch_hidden.data_ptr(), engine.batch_action.data_ptr(), engine._stream()))
+        else:
+            engine._check(lib.mzmcts_expand_backup_injected(h, value.data_ptr(), reward.data_ptr(), priors.data_ptr(), engine._stream()))
     return engine.readout()
 
 move()
@@ -53,6 +60,11 @@ for name, ms, n, per in (("select", "select_ms", "select_launches", b["select"])
     us = 1e3 * prof[ms] / prof[n]
     out["kernels"][name] = {"avg_us": us, "launches": prof[n], "algorithmic_bytes_per_launch": per * E,
                             "achieved_GBs": per * E / (us * 1e-6) / 1e9, "frac_of_8TBs": per * E / (us * 1e-6) / 8e12}
+if prof["step_launches"]:
+    us = 1e3 * prof["step_ms"] / prof["step_launches"]
+    per = b["select"] + b["expand_backup"]
+    out["kernels"]["expand_backup_select"] = {"avg_us": us, "launches": prof["step_launches"], "algorithmic_bytes_per_launch": per * E,
+                                              "achieved_GBs": per * E / (us * 1e-6) / 1e9, "frac_of_8TBs": per * E / (us * 1e-6) / 8e12}
 out["tree_sims_per_s_kernels_only"] = E / ((out["kernels"]["select"]["avg_us"] + out["kernels"]["expand_backup"]["avg_us"]) * 1e-6)
 print(json.dumps(out))
 engine.close()
