@@ -23,11 +23,40 @@ def cartpole_setup(pkg, ties):
     models = importlib.import_module("muzero-hypermodel_amd.models")
     config = importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
     model, _ = cartpole_model_and_weights(models, config, "cuda")
-    if ties:   # all-equal priors below the root: the search breaks ties with the RNG all the time (fixture G5 recipe)
+    if ties is True:   # all-equal priors below the root: the search breaks ties with the RNG all the time (fixture G5 recipe)
         with torch.no_grad():
             for name, prm in model.named_parameters():
                 if name.startswith("prediction_policy_network.module.2"):
                     prm.zero_()
+    elif ties == "some":
+        # Priors tie at SOME nodes only: the two policy logits differ by exactly one hidden unit of the policy MLP, and that
+        # unit is ELU(encoded_state[c]) -- zero exactly where component c is the state's minimum (the min-max rescale maps
+        # it to 0.0).  A search then spends extra tie-break words at unpredictable moves, so an env leaves the pre-drawn path
+        # at every position of a batch sooner or later: the host mirror's rewind (restore_stream / draw_env_rows,
+        # csrc/mzmcts_moves.hip) is exercised at each of them.
+        with torch.no_grad():
+            prm = dict(model.named_parameters())
+            w1, b1 = prm["prediction_policy_network.module.0.weight"], prm["prediction_policy_network.module.0.bias"]
+            w2, b2 = prm["prediction_policy_network.module.2.weight"], prm["prediction_policy_network.module.2.bias"]
+            # c: a component that is the minimum at some search nodes but not at most (counted over a few random walks)
+            rs = np.random.RandomState(0)
+            obs = torch.from_numpy(rs.uniform(-0.05, 0.05, (64, 4)).astype(np.float32)).to(w1.device)
+            state = model.representation(obs)
+            counts = np.zeros(state.shape[1])
+            for _ in range(6):
+                counts += np.bincount(state.argmin(1).cpu().numpy(), minlength=state.shape[1])
+                action = torch.from_numpy(rs.randint(0, 2, (64, 1))).to(w1.device)
+                state, _ = model.dynamics(state, action)
+            share = counts / counts.sum()
+            c = int(np.argmin(np.abs(share - 0.08)))
+            assert 0.02 < share[c] < 0.5, share
+            u = 3
+            w1[u].zero_()
+            w1[u, c] = 1.0
+            b1[u] = 0.0
+            w2[1].copy_(w2[0])
+            b2[1] = b2[0]
+            w2[0, u] += 1.0
     return config, model
 
 
@@ -40,10 +69,14 @@ def cartpole_setup(pkg, ties):
     (16, "narrow", False, "mixed", 5, True),
     (4, "generic", False, "one", 3, False),
     (4, "generic", True, "mixed", 3, True),
+    (16, "narrow", "some", "one", 6, False),   # mis-speculation at every position of a batch (see cartpole_setup)
+    (16, "narrow", "some", "one", 6, True),
+    (16, "narrow", "some", "mixed", 5, True),
 ])
 def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, temps, batch, overlap):
     config, model = cartpole_setup(pkg, ties)
     E, N = 83, 40 if ties else 24            # N moves per env: > 624 RNG words per env when ties abound
+    stalled_at = set()                       # batch positions at which some env left the pre-drawn path
     rs = np.random.RandomState(4)
     obs = torch.from_numpy(rs.uniform(-0.05, 0.05, (E, 4)).astype(np.float32)).cuda()   # same observation every move
     legal = [[0, 1] if e % 11 else [] for e in range(E)]                                # a few inactive envs
@@ -55,8 +88,19 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
     ref.configure_fused_fc(model)
     ref.set_fused_options(variant, publish_tree=False)
     want = []
-    for _ in range(N + batch + 6):
-        st = ref.search_fused(obs, legal, to_play, True)
+    total = N + batch + 6
+    if ties == "some":    # a different observation every move, so the tying nodes -- and the stalls -- move around
+        every = torch.from_numpy(rs.uniform(-0.05, 0.05, (total, E, 4)).astype(np.float32)).cuda()
+    else:
+        every = obs.expand(total, E, 4)
+    lanes = torch.arange(E, device="cuda")
+
+    def obs_at(m):        # batch position m: every env sees the observation of ITS next move
+        at = torch.tensor([min(len(g) + m, total - 1) for g in got], device="cuda")
+        return every[at, lanes].contiguous()
+
+    for i in range(total):
+        st = ref.search_fused(every[i].contiguous(), legal, to_play, True)
         actions, _ = ref.sample_actions(T)
         want.append((actions.copy(), st["visits"].copy(), st["root_value_sum"].copy(),
                      st["root_predicted_value"].copy(), st["max_tree_depth"].copy()))
@@ -73,13 +117,13 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
         engine.moves_prepare(batch, legal, to_play, T, True)
     while min(len(got[e]) for e in active) < N:
         if overlap:
-            for _ in range(batch):
-                engine.moves_enqueue(obs)
+            for m in range(batch):
+                engine.moves_enqueue(obs_at(m))
             engine.moves_predraw_next(batch, legal, to_play, T, True)
             out = engine.moves_collect(copy=False)        # views of the pinned download ring
             engine.moves_submit_next()
         else:
-            out = engine.run_moves([obs] * batch, legal, to_play, T, True)
+            out = engine.run_moves([obs_at(m) for m in range(batch)], legal, to_play, T, True)
         rounds += 1
         assert rounds <= 2 * N + 4
         for e in range(E):
@@ -87,6 +131,8 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
             assert (k >= 1) == bool(legal[e]) and (k == len(out["actions"]) or out["actions"][k, e] == -1)
             if np.isinf(T[e]) and legal[e]:
                 assert k == 1
+            elif legal[e] and k < len(out["actions"]):
+                stalled_at.add(int(k))
             for m in range(k):
                 got[e].append((out["actions"][m, e], out["visits"][m, e].copy(), out["root_value_sum"][m, e],
                                out["root_predicted"][m, e], out["max_depth"][m, e]))
@@ -94,19 +140,24 @@ def test_move_batches_equal_one_move_at_a_time(eng, pkg, group, variant, ties, t
         engine.moves_collect()             # the batch submitted last: nothing enqueued, every draw is undone
         # a pre-drawn batch that is dropped must leave the streams where a fresh engine's would be
         engine.moves_prepare(2, legal, to_play, T, True)
-        engine.moves_enqueue(obs), engine.moves_enqueue(obs)
+        engine.moves_enqueue(obs_at(0)), engine.moves_enqueue(obs_at(1))
         engine.moves_predraw_next(batch, legal, to_play, T, True)
         a = engine.moves_collect()
         engine.moves_discard_next()
-        b = engine.run_moves([obs] * 2, legal, to_play, T, True)
         for e in active:
-            seq = [(a, m) for m in range(a["moves_done"][e])] + [(b, m) for m in range(b["moves_done"][e])]
-            for i, (o, m) in enumerate(seq):
-                n = len(got[e])
+            for m in range(a["moves_done"][e]):
+                got[e].append((a["actions"][m, e], a["visits"][m, e].copy(), a["root_value_sum"][m, e],
+                               a["root_predicted"][m, e], a["max_depth"][m, e]))
+        b = engine.run_moves([obs_at(0), obs_at(1)], legal, to_play, T, True)
+        for e in active:
+            for o, m in [(b, m) for m in range(b["moves_done"][e])]:
                 got[e].append((o["actions"][m, e], o["visits"][m, e].copy(), o["root_value_sum"][m, e],
                                o["root_predicted"][m, e], o["max_depth"][m, e]))
     engine.close()
-    if ties:
+    if ties == "some":
+        # every position of the batch saw an env stall (its mirror rewound to the state after the last noise row used)
+        assert stalled_at >= set(range(1, batch)), sorted(stalled_at)
+    elif ties:
         assert rounds >= N // 2             # the tie-breaking searches really did stall the batches
     else:
         assert rounds <= (N // batch + 3) * (batch if temps == "mixed" else 1)
