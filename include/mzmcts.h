@@ -405,6 +405,12 @@ int mzmcts_board_tower_split(const float *x, int64_t batch, int32_t cin0, int32_
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
+/* Trees each wavefront of mzmcts_select works through (self_play.py:321-335 is one descent; the trees are independent,
+ * so the order they are descended in changes no result).  0 or 1 = one descent per lane group (default);
+ * n > 64 / lanes-per-tree = a wavefront-local queue of n trees whose lane groups pick up the next tree when their
+ * descent ends instead of idling behind the deepest one (measured slower at E = 2^20: the kernel is bound by the
+ * memory system's request rate). */
+int mzmcts_set_select_queue(mzmcts_engine *engine, int32_t trees_per_wavefront);
 int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset); /* blocking */
 /* Bytes of device memory the engine's pools occupy (node blocks, hidden pool, RNG, paths). */
 int64_t mzmcts_device_bytes(const mzmcts_engine *engine);

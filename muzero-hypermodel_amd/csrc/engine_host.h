@@ -51,8 +51,8 @@ hipError_t launch_fc_inference_narrow(const TreeParams& p, const FcNet& net, con
 hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const FusedLayout& lay, const float* weights,
                                   const float* observations, const MoveCtl& ctl, int n_sims, hipStream_t stream,
                                   const LaunchTiming* timing);
-hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
-                         const LaunchTiming* timing);
+hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, int queue_trees,
+                         hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
                                         hipStream_t stream);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -249,6 +249,7 @@ struct mzmcts_engine {
 
     // profiling
     bool profiling = false;
+    int select_queue_trees = 0;      // mzmcts_set_select_queue: 0 = one descent per lane group
     std::vector<EventPair> events;
     size_t events_used = 0;
     mzmcts_profile prof{};

@@ -251,13 +251,15 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         if (ctl.depth_sum) ctl.depth_sum[e] = static_cast<int32_t>(depth_sum);
     }
     if (ctl.visits && j < p.A) ctl.visits[static_cast<size_t>(e) * p.A + j] = (j < n_root) ? tree.links(0)[j].visits : 0;
-    const int block_words = static_cast<int>(p.block_stride / 16);
+    // (in LDS a block is two member arrays, in HBM an array of 32-byte child records: word i of the one is stats[i] or
+    // links[i - A], word 2 c / 2 c + 1 of the other the stats / links of child c)
+    const int block_words = 2 * p.A;
     const int n_blocks = publish_tree ? n_sims + 1 : 1;
     for (int t = j; t < n_blocks * block_words; t += kRow) {
         const int k = t / block_words, i = t - k * block_words;
         const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
         uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.line_stride);   // own line, half 0
-        dst[i] = src[i];
+        dst[i < p.A ? 2 * i : 2 * (i - p.A) + 1] = src[i];
     }
     for (int t = j; t < n_blocks * enc; t += kRow) {
         const int k = t / enc, i = t - k * enc;

@@ -64,6 +64,9 @@ __device__ __forceinline__ void select_tree(const TreeParams& p, int sim, const 
 
     const GlobalTree tree = global_tree(p, e);
     uint32_t words = 0;
+    // (Tried for paired lines: fetching the whole 128-byte line per level and taking hops into its other half from
+    // registers -- 294 us against 258 us at E = 2^20: the second half already comes out of L2, the registers cost a
+    // wavefront per SIMD.)
     const Descent d = descend<G, CH>(tree, pbc_table, p.S, p.A, sim, n_root, mm, p.discount, p.P == 2,
                                      p.mt_key + static_cast<size_t>(e) * kMtN, mt_pos, words, j, group_base,
                                      p.path_ties ? p.path_ties + e : nullptr, p.E, p.error_flag);
@@ -122,6 +125,176 @@ __global__ __launch_bounds__(kThreads, 8) void select_kernel(TreeParams p, int s
     __syncthreads();
     if (!in_range) return;
     select_tree<G, CH, FUSE_GATHER>(p, sim, pbc_table, e, j, group_base, n_root, mm, mt_pos, hidden_out, action_out);
+}
+
+// -------------------------------------------------------------------------------------------------
+// select for MANY trees per wavefront (an experiment for HBM scale, off unless mzmcts_set_select_queue asks for it).
+// A wavefront of select_kernel lasts as long as the DEEPEST of its 64/G descents while the mean descent is about half
+// as long: half of the lane groups idle behind a finished tree.  Here a wavefront owns `trees_per_wave` consecutive trees and its
+// lane groups draw them from a wavefront-local queue: one loop iteration = one level of whatever tree each group is
+// in, a group whose descent ended takes the next tree of the queue in the same iteration.  Per-tree inputs (min-max
+// bounds, root child count, RNG cursor) are staged in LDS up front and the per-tree outputs collected there, so a
+// tree change costs no dependent global load; the hidden-state gather runs at the end with all rows in flight.
+// Trees are independent, so the order they are descended in changes nothing (tests: bit-identical to select_kernel).
+// -------------------------------------------------------------------------------------------------
+union QueueSlot {       // per tree of the wavefront: input, then output of the same tree
+    MinMax mm;          // in
+    int4 out;           // out: {path_len, leaf_parent, leaf_loc, action}
+};
+constexpr size_t kQueueBytesPerTree = sizeof(QueueSlot) + 2 * sizeof(int32_t);   // + root child count, RNG cursor
+
+template <int G, int CH, bool FUSE_GATHER>
+__global__ __launch_bounds__(kThreads, 8) void select_queue_kernel(TreeParams p, int sim, int trees_per_wave,
+                                                                   float* __restrict__ hidden_out,
+                                                                   int64_t* __restrict__ action_out) {
+    extern __shared__ double queue_smem[];  // pb_c table [2][S+1] | QueueSlot [T] | n_root i32 [T] | mt_pos i32 [T]
+    constexpr int kTrees = kThreads / G;
+    double* pbc_table = queue_smem;
+    QueueSlot* slots = reinterpret_cast<QueueSlot*>(queue_smem + 2 * (p.S + 1));
+    int32_t* slot_n_root = reinterpret_cast<int32_t*>(slots + trees_per_wave);
+    int32_t* slot_mt_pos = slot_n_root + trees_per_wave;
+    const int base = blockIdx.x * trees_per_wave;
+    const int count = (p.E - base < trees_per_wave) ? p.E - base : trees_per_wave;
+    for (int t = threadIdx.x; t < count; t += kThreads) {
+        slots[t].mm = p.min_max[base + t];
+        slot_n_root[t] = p.root_children[base + t];
+        slot_mt_pos[t] = p.mt_pos[base + t];
+    }
+    stage_pbc_table(pbc_table, p);
+    __syncthreads();
+
+    const int j = threadIdx.x % G;
+    const int group_base = threadIdx.x - j;
+    const int span = child_span<G>(p.A);
+    const bool two_player = p.P == 2;
+    const bool paired = p.line_stride != p.block_stride;
+    int next = kTrees;           // first tree of the queue nobody has taken yet (wavefront-uniform)
+    int t = threadIdx.x / G;     // this group's tree, relative to base
+    bool active = t < count;
+    // the descent this group is in
+    int e = base + t, n_children = 0, k = 0, loc = 0, N = sim, depth = 0;
+    MinMax mm{};
+    int32_t mt_pos = 0;
+    uint32_t words = 0;
+    if (active) {
+        mm = slots[t].mm;
+        n_children = slot_n_root[t];
+        mt_pos = slot_mt_pos[t];
+    }
+    while (__ballot(active) != 0ull) {
+        bool finished = false;
+        if (active) {
+            const GlobalTree tree = global_tree(p, e);
+            int4 out{0, 0, 0, 0};
+            if (n_children == 0) {  // inactive tree: keep the batch row defined
+                finished = true;
+            } else {
+                const LevelPick pick = select_level<G, CH>(tree, pbc_table, p.S, p.A, loc, N, n_children, span, mm, p.discount,
+                                                           two_player, p.mt_key + static_cast<size_t>(e) * kMtN, mt_pos, words,
+                                                           j, group_base, p.error_flag);
+                if (j == 0) {
+                    tree.path_store(depth, (loc << 8) | pick.slot);
+                    if (p.path_ties) p.path_ties[static_cast<size_t>(depth) * p.E + e] = pick.n_ties;
+                }
+                ++depth;
+                if (pick.child < 0 || depth > sim) {
+                    finished = true;
+                    if (pick.child >= 0 && j == 0) atomicOr(p.error_flag, 2);  // inconsistent tree (see descend)
+                    // where the node this simulation expands will live (see select_tree)
+                    const bool first_child = N == (k == 0 ? 0 : 1);
+                    out.x = depth;
+                    out.y = k;
+                    out.z = (paired && first_child && (loc & 1) == 0) ? (loc | 1) : 2 * (sim + 1);
+                    out.w = (depth == 1) ? p.root_action[static_cast<size_t>(e) * p.A + pick.slot] : pick.slot;
+                    if (j == 0 && words) {
+                        p.mt_pos[e] = mt_pos;
+                        p.tie_words[e] += words;
+                    }
+                } else {
+                    k = pick.child;
+                    loc = pick.loc;
+                    N = pick.visits;
+                    n_children = p.A;
+                }
+            }
+            if (finished && j == 0) slots[t].out = out;
+        }
+        // groups whose descent ended take the next trees of the queue, in lane order
+        const unsigned long long fin = __ballot(finished && j == 0);
+        if (finished) {
+            const int rank = __popcll(fin & ((1ull << group_base) - 1ull));
+            t = next + rank;
+            active = t < count;
+            if (active) {
+                e = base + t;
+                mm = slots[t].mm;
+                n_children = slot_n_root[t];
+                mt_pos = slot_mt_pos[t];
+                words = 0;
+                k = 0;
+                loc = 0;
+                N = sim;
+                depth = 0;
+            }
+        }
+        next += __popcll(fin);
+    }
+    __syncthreads();
+
+    // per-tree results, coalesced
+    for (int r = threadIdx.x; r < count; r += kThreads) {
+        const int4 out = slots[r].out;
+        p.path_len[base + r] = out.x;
+        p.leaf_parent[base + r] = out.y;
+        p.leaf_loc[base + r] = out.z;
+        if (action_out) action_out[base + r] = out.w;
+    }
+    // hidden-state gather (self_play.py:339-343): every row's loads in flight together
+    if (FUSE_GATHER && hidden_out) {
+        constexpr int kBatch = 4;
+        if ((p.H & 3) == 0) {
+            const int h4 = p.H / 4;
+            const int pieces = count * h4;
+            for (int i0 = threadIdx.x; i0 < pieces; i0 += kThreads * kBatch) {
+                float4 v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int i = i0 + u * kThreads;
+                    v[u] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (i < pieces) {
+                        const int r = i / h4, c = i - r * h4;
+                        if (slots[r].out.x > 0)
+                            v[u] = reinterpret_cast<const float4*>(
+                                p.hidden + (static_cast<size_t>(slots[r].out.y) * p.E + base + r) * p.H)[c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int i = i0 + u * kThreads;
+                    if (i < pieces) reinterpret_cast<float4*>(hidden_out + static_cast<size_t>(base) * p.H)[i] = v[u];
+                }
+            }
+        } else {
+            const int pieces = count * p.H;
+            for (int i0 = threadIdx.x; i0 < pieces; i0 += kThreads * kBatch) {
+                float v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int i = i0 + u * kThreads;
+                    v[u] = 0.f;
+                    if (i < pieces) {
+                        const int r = i / p.H, c = i - r * p.H;
+                        if (slots[r].out.x > 0) v[u] = p.hidden[(static_cast<size_t>(slots[r].out.y) * p.E + base + r) * p.H + c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int i = i0 + u * kThreads;
+                    if (i < pieces) hidden_out[static_cast<size_t>(base) * p.H + i] = v[u];
+                }
+            }
+        }
+    }
 }
 
 // Stand-alone gather for large hidden states (ResNet planes): one workgroup row per tree,
@@ -588,11 +761,12 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
     if (ctl.visits)
         for (int c = j; c < p.A; c += G)
             ctl.visits[static_cast<size_t>(e) * p.A + c] = (c < n_root) ? tree.links(0)[c].visits : 0;
-    const int block_words = static_cast<int>(p.block_stride / 16);
+    // (in LDS a block is two member arrays, in HBM an array of 32-byte child records: word i of the one is stats[i] or
+    // links[i - A], word 2 c / 2 c + 1 of the other the stats / links of child c)
     for (int k = 0; k <= n_sims; ++k) {
         const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
         uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.line_stride);   // own line, half 0
-        for (int i = j; i < block_words; i += G) dst[i] = src[i];
+        for (int i = j; i < 2 * p.A; i += G) dst[i < p.A ? 2 * i : 2 * (i - p.A) + 1] = src[i];
     }
     MZ_STAMP(7);
     MZ_STAMP_FLUSH;
@@ -648,15 +822,35 @@ static inline int tree_grid(const TreeParams& p) {
 
 constexpr int kFuseGatherMaxFloats = 64;
 
-hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, hipStream_t stream,
-                         const LaunchTiming* timing) {
+// Trees per wavefront of the select kernel (mzmcts_set_select_queue): 64/G, one descent per lane group, unless the
+// caller asks for a wavefront-local queue (select_queue_kernel).  Measured at E = 2^20 (profiles/r02_select_queue.jsonl):
+// 258 us without a queue, 297 / 309 / 271 us with 64 / 128 / 256 trees per wavefront -- the kernel runs at the memory
+// system's request rate, not at the length of its longest descent, so the queue stays off unless requested.
+static int select_queue_trees(const TreeParams& p, int requested) {
+    const int per_wave = kThreads / p.group;
+    if (p.A > 64 || requested <= per_wave) return per_wave;
+    return requested;
+}
+
+hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, int queue_request,
+                         hipStream_t stream, const LaunchTiming* timing) {
     const size_t lds = sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1);
     const int grid = tree_grid(p);
     const bool fuse = p.H <= kFuseGatherMaxFloats;
+    const int queue_trees = select_queue_trees(p, queue_request);
     dispatch_group(p, [&](auto g, auto ch) {
         constexpr int G = decltype(g)::value;
         constexpr int CH = decltype(ch)::value;
-        if (fuse)
+        if (queue_trees > kThreads / G) {
+            const size_t qlds = lds + kQueueBytesPerTree * static_cast<size_t>(queue_trees);   // (lds = 16 (S + 1) bytes)
+            const int qgrid = (p.E + queue_trees - 1) / queue_trees;
+            if (fuse)
+                launch_kernel(select_queue_kernel<G, CH, true>, dim3(qgrid), dim3(kThreads), qlds, stream, timing, p, sim,
+                              queue_trees, hidden_out, action_out);
+            else
+                launch_kernel(select_queue_kernel<G, CH, false>, dim3(qgrid), dim3(kThreads), qlds, stream, timing, p, sim,
+                              queue_trees, hidden_out, action_out);
+        } else if (fuse)
             launch_kernel(select_kernel<G, CH, true>, dim3(grid), dim3(kThreads), lds, stream, timing, p, sim, hidden_out,
                           action_out);
         else

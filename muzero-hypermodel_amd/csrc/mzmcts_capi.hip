@@ -336,8 +336,8 @@ int mzmcts_select(mzmcts_engine* eng, float* parent_hidden_out, int64_t* action_
     if (eng->sim >= eng->p.S) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select: all simulations already ran");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope scope(eng, stream, kProfSelect);
-    MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out, stream,
-                                  scope.get()));
+    MZ_HIP(eng, mz::launch_select(eng->p, eng->sim, eng->p.H > 0 ? parent_hidden_out : nullptr, action_out,
+                                  eng->select_queue_trees, stream, scope.get()));
     return MZMCTS_OK;
 }
 
@@ -502,20 +502,19 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
         int64_t local_depth = 0, local_active = 0;
         for (int e = lo; e < hi; ++e) {
             const uint8_t* blk = eng->h_slab0 + static_cast<size_t>(e) * p.line_stride;   // the root's block: half 0 of line (0, e)
-            const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
-            const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
+            const mz::HbmChild* rec = reinterpret_cast<const mz::HbmChild*>(blk);
             const int n = eng->h_nlegal[e];
             const bool is_active = n > 0;
             for (int i = 0; i < A; ++i) {
                 const size_t o = static_cast<size_t>(e) * A + i;
                 const bool live = i < n;
-                eng->last_visits[o] = live ? lk[i].visits : 0;
+                eng->last_visits[o] = live ? rec[i].links.visits : 0;
                 if (out) {
-                    if (out->visits) out->visits[o] = live ? lk[i].visits : 0;
-                    if (out->child_value_sum) out->child_value_sum[o] = live ? st[i].value_sum : 0.0;
-                    if (out->child_prior) out->child_prior[o] = live ? st[i].prior : 0.0;
-                    if (out->child_reward) out->child_reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
-                    if (out->child_expanded) out->child_expanded[o] = (live && lk[i].child_node >= 0) ? 1 : 0;
+                    if (out->visits) out->visits[o] = live ? rec[i].links.visits : 0;
+                    if (out->child_value_sum) out->child_value_sum[o] = live ? rec[i].stats.value_sum : 0.0;
+                    if (out->child_prior) out->child_prior[o] = live ? rec[i].stats.prior : 0.0;
+                    if (out->child_reward) out->child_reward[o] = live ? static_cast<double>(rec[i].links.reward) : 0.0;
+                    if (out->child_expanded) out->child_expanded[o] = (live && rec[i].links.child_node >= 0) ? 1 : 0;
                 }
             }
             eng->last_root_value_sum[e] = is_active ? eng->h_root_value_sum[e] : 0.0;
@@ -655,20 +654,19 @@ int mzmcts_export_tree(mzmcts_engine* eng, int32_t env, int32_t* visits, double*
         const int loc = loc_of[k];                       // (parents have smaller expansion indices than their children)
         const bool placed = loc >= 0 && (loc >> 1) < K;
         const uint8_t* blk = buf.data() + static_cast<size_t>(placed ? (loc >> 1) : 0) * p.line_stride + (placed ? (loc & 1) * 64u : 0u);
-        const mz::ChildStats* st = reinterpret_cast<const mz::ChildStats*>(blk);
-        const mz::ChildLinks* lk = reinterpret_cast<const mz::ChildLinks*>(blk + p.links_offset);
+        const mz::HbmChild* rec = reinterpret_cast<const mz::HbmChild*>(blk);
         if (placed && k <= eng->sim)
             for (int i = 0; i < (k == 0 ? n_root : A); ++i)
-                if (lk[i].child_node > k && lk[i].child_node < K) loc_of[lk[i].child_node] = lk[i].block_loc;
+                if (rec[i].links.child_node > k && rec[i].links.child_node < K) loc_of[rec[i].links.child_node] = rec[i].links.block_loc;
         const bool written = placed && k <= eng->sim;
         for (int i = 0; i < A; ++i) {
             const size_t o = static_cast<size_t>(k) * A + i;
             const bool live = written && (k > 0 || i < n_root);
-            if (visits) visits[o] = live ? lk[i].visits : 0;
-            if (value_sum) value_sum[o] = live ? st[i].value_sum : 0.0;
-            if (prior) prior[o] = live ? st[i].prior : 0.0;
-            if (reward) reward[o] = live ? static_cast<double>(lk[i].reward) : 0.0;
-            if (child_node) child_node[o] = live ? lk[i].child_node : -1;
+            if (visits) visits[o] = live ? rec[i].links.visits : 0;
+            if (value_sum) value_sum[o] = live ? rec[i].stats.value_sum : 0.0;
+            if (prior) prior[o] = live ? rec[i].stats.prior : 0.0;
+            if (reward) reward[o] = live ? static_cast<double>(rec[i].links.reward) : 0.0;
+            if (child_node) child_node[o] = live ? rec[i].links.child_node : -1;
         }
     }
     return MZMCTS_OK;
@@ -936,6 +934,14 @@ int mzmcts_debug_read_stamps(unsigned long long* out, int32_t reset) {
 int mzmcts_set_profiling(mzmcts_engine* eng, int32_t enabled) {
     if (!eng) return MZMCTS_ERR_INVALID;
     eng->profiling = enabled != 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_set_select_queue(mzmcts_engine* eng, int32_t trees_per_wavefront) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (trees_per_wavefront < 0 || trees_per_wavefront > 4096)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_select_queue: trees_per_wavefront must be in [0, 4096]");
+    eng->select_queue_trees = trees_per_wavefront;
     return MZMCTS_OK;
 }
 

@@ -87,19 +87,32 @@ __device__ __forceinline__ void group_memory_fence() {
 
 // ---- storage policies ---------------------------------------------------------------------------
 // Blocks are addressed by LOCATION loc = 2 * slab + half (ChildLinks::block_loc); the root's is 0.
+//
+// In HBM a block is an array of 32-byte CHILD RECORDS { ChildStats, ChildLinks } (tree_layout.h): everything the
+// backup reads and rewrites of a path node -- value_sum, reward, visits -- sits in ONE 32-byte sector, the unit the
+// memory system fetches and writes back.  Records<T> is a pointer to member T of consecutive records: it indexes
+// and offsets like the plain T* the LDS-resident trees hand out (which keep the two members as separate arrays).
+template <typename T>
+struct Records {
+    uint8_t* base;
+    __device__ __forceinline__ T& operator[](int child) const {
+        return *reinterpret_cast<T*>(base + static_cast<uint32_t>(child) * kChildRecordBytes);
+    }
+    __device__ __forceinline__ T* operator+(int child) const { return &(*this)[child]; }
+};
+
 struct GlobalTree {
     static constexpr bool kInLds = false;
     uint8_t* blocks;       // p.blocks + e * line_stride
     size_t slab_stride;    // E * line_stride
-    uint32_t links_offset;
     int32_t* path;         // p.path + e
     int E;
     __device__ __forceinline__ uint8_t* block(int loc) const {
         return blocks + static_cast<size_t>(loc >> 1) * slab_stride + static_cast<size_t>(loc & 1) * 64u;
     }
-    __device__ __forceinline__ ChildStats* stats(int loc) const { return reinterpret_cast<ChildStats*>(block(loc)); }
-    __device__ __forceinline__ ChildLinks* links(int loc) const {
-        return reinterpret_cast<ChildLinks*>(block(loc) + links_offset);
+    __device__ __forceinline__ Records<ChildStats> stats(int loc) const { return Records<ChildStats>{block(loc)}; }
+    __device__ __forceinline__ Records<ChildLinks> links(int loc) const {
+        return Records<ChildLinks>{block(loc) + sizeof(ChildStats)};
     }
     __device__ __forceinline__ void path_store(int level, int packed) const {
         path[static_cast<size_t>(level) * E] = packed;
@@ -109,7 +122,7 @@ struct GlobalTree {
 
 __device__ __forceinline__ GlobalTree global_tree(const TreeParams& p, int e) {
     return GlobalTree{p.blocks + static_cast<size_t>(e) * p.line_stride, static_cast<size_t>(p.E) * p.line_stride,
-                      p.links_offset, p.path + e, p.E};
+                      p.path + e, p.E};
 }
 
 struct LdsTree {
@@ -154,16 +167,144 @@ struct Descent {
     int parent_visits;  // its visit count before this simulation
 };
 
+// What one select_child call (self_play.py:364-379) decides, known to every lane of the group.
+struct LevelPick {
+    int slot;     // chosen child slot
+    int visits;   // its visit count
+    int child;    // its expanded-node index, -1 = not expanded (the descent ends here)
+    int loc;      // where its own block lives
+    int n_ties;   // size of the tie list the choice was drawn from
+};
+
+// select_child (self_play.py:364-379) over the child records a lane group holds: lane j has children c * G + j in
+// st[c] / lk[c] (records of slots >= n_children are ignored).  N = the node's visit count.  pbc_table: [2][S+1] in
+// LDS.  The group leader owns the RNG cursor (mt_pos / words).
+template <int G, int CH>
+__device__ __forceinline__ LevelPick pick_child(const ChildStats (&st)[CH], ChildLinks (&lk)[CH], const double* pbc_table,
+                                                int S, int N, int n_children, int span, const MinMax& mm, double discount,
+                                                bool two_player, uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j,
+                                                int group_base, int32_t* error_flag) {
+    const double pb_log = pbc_table[N];
+    const double pb_sqrt = pbc_table[S + 1 + N];
+
+    double score[CH];
+    double best = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int child = c * G + j;
+        score[c] = -INFINITY;
+        if (child < n_children) {
+            score[c] = ucb_score(pb_log, pb_sqrt, st[c], lk[c], discount, two_player, mm.minimum, mm.maximum);
+            best = fmax(best, score[c]);
+        } else {
+            lk[c] = ChildLinks{0.f, 0, -1, 0};
+        }
+    }
+    best = group_max<G>(best, span);
+
+    // tie list in child order (self_play.py:372-378)
+    unsigned long long tie_mask[CH];
+    int n_ties = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const bool is_max = (c * G + j < n_children) && (score[c] == best);
+        const unsigned long long ballot = __ballot(is_max);
+        if constexpr (G == 64)
+            tie_mask[c] = ballot;
+        else
+            tie_mask[c] = (ballot >> group_base) & ((1ull << G) - 1ull);
+        n_ties += __popcll(tie_mask[c]);
+    }
+    int pick = 0;
+    if (n_ties > 1) {
+        uint32_t r = 0;
+        if (j == 0) r = mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words);
+        pick = static_cast<int>(__shfl(r, 0, G));
+    } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
+        if (j == 0) atomicOr(error_flag, 1);
+        tie_mask[0] = 1ull;
+    }
+    int slot = 0, sel_visits = 0, sel_child = -1, sel_loc = 0;
+    {
+        int remaining = pick;
+        bool found = false;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            unsigned long long m = tie_mask[c];
+            const int cnt = __popcll(m);
+            if (!found && remaining < cnt) {
+                for (int i = 0; i < remaining; ++i) m &= m - 1ull;
+                const int bit = __ffsll(static_cast<long long>(m)) - 1;
+                slot = c * G + bit;
+                // the chosen lane publishes its child's links to the group with an OR-butterfly of DPP
+                // moves (child_node is biased by 1 so that "not expanded" (-1) contributes zero bits)
+                int pub_visits = (j == bit) ? lk[c].visits : 0;
+                int pub_child = (j == bit) ? lk[c].child_node + 1 : 0;
+                int pub_loc = (j == bit) ? lk[c].block_loc : 0;
+                if constexpr (G <= 16) {
+                    // over the whole group, so that every lane ends up with the values
+                    MZ_BUTTERFLY(G, G, (pub_visits |= partner_bits<M>(pub_visits),
+                                        pub_child |= partner_bits<M>(pub_child),
+                                        pub_loc |= partner_bits<M>(pub_loc)));
+                } else {
+                    pub_visits = __shfl(lk[c].visits, bit, G);
+                    pub_child = __shfl(lk[c].child_node, bit, G) + 1;
+                    pub_loc = __shfl(lk[c].block_loc, bit, G);
+                }
+                sel_visits = pub_visits;
+                sel_child = pub_child - 1;
+                sel_loc = pub_loc;
+                found = true;
+            } else if (!found) {
+                remaining -= cnt;  // (found / remaining are uniform across the group's lanes)
+            }
+        }
+    }
+    return LevelPick{slot, sel_visits, sel_child, sel_loc, n_ties};
+}
+
+// One level of the descent: select_child at the node whose block lives at `loc` (N = its visit count, n_children of
+// its A slots are children).  Records are loaded for every slot of the block (a masked root has all A slots
+// initialised), so that the loads do not wait for n_children.
+template <int G, int CH, typename Acc>
+__device__ __forceinline__ LevelPick select_level(const Acc& acc, const double* pbc_table, int S, int A, int loc, int N,
+                                                  int n_children, int span, const MinMax& mm, double discount,
+                                                  bool two_player, uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j,
+                                                  int group_base, int32_t* error_flag) {
+    const auto stats = acc.stats(loc);
+    const auto links = acc.links(loc);
+    ChildStats st[CH];
+    ChildLinks lk[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int child = c * G + j;
+        st[c] = ChildStats{0.0, 0.0};
+        lk[c] = ChildLinks{0.f, 0, -1, 0};
+        if (child < A) {
+            st[c] = stats[child];
+            lk[c] = links[child];
+        }
+    }
+    return pick_child<G, CH>(st, lk, pbc_table, S, N, n_children, span, mm, discount, two_player, mt_key, mt_pos, words, j,
+                             group_base, error_flag);
+}
+
+// lanes that can hold a child: pow2 >= min(A, G)
+template <int G>
+__device__ __forceinline__ int child_span(int A) {
+    int span = 1;
+    while (span < A && span < G) span <<= 1;
+    return span;
+}
+
 // The `while node.expanded()` loop (self_play.py:321-335) with select_child (self_play.py:364-379).
-// pbc_table: [2][S+1] in LDS.  The group leader owns the RNG cursor (mt_pos / words).
 template <int G, int CH, typename Acc>
 __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_table, int S, int A, int sim,
                                            int n_root_children, const MinMax& mm, double discount, bool two_player,
                                            uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j, int group_base,
                                            int32_t* path_ties /* this tree's column or null */, int ties_stride,
                                            int32_t* error_flag) {
-    int span = 1;  // lanes that can hold a child: pow2 >= min(A, G)
-    while (span < A && span < G) span <<= 1;
+    const int span = child_span<G>(A);
     int n_children = n_root_children;
     int k = 0;    // expanded-node index of the current parent
     int loc = 0;  // where its block lives
@@ -171,99 +312,22 @@ __device__ __forceinline__ Descent descend(const Acc& acc, const double* pbc_tab
     int depth = 0;
     int slot = 0;
     for (;;) {
-        const ChildStats* stats = acc.stats(loc);
-        const ChildLinks* links = acc.links(loc);
-        const double pb_log = pbc_table[N];
-        const double pb_sqrt = pbc_table[S + 1 + N];
-
-        double score[CH];
-        ChildLinks lk[CH];
-        double best = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int child = c * G + j;
-            score[c] = -INFINITY;
-            lk[c] = ChildLinks{0.f, 0, -1, 0};
-            if (child < n_children) {
-                const ChildStats st = stats[child];
-                lk[c] = links[child];
-                score[c] = ucb_score(pb_log, pb_sqrt, st, lk[c], discount, two_player, mm.minimum, mm.maximum);
-                best = fmax(best, score[c]);
-            }
-        }
-        best = group_max<G>(best, span);
-
-        // tie list in child order (self_play.py:372-378)
-        unsigned long long tie_mask[CH];
-        int n_ties = 0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const bool is_max = (c * G + j < n_children) && (score[c] == best);
-            const unsigned long long ballot = __ballot(is_max);
-            if constexpr (G == 64)
-                tie_mask[c] = ballot;
-            else
-                tie_mask[c] = (ballot >> group_base) & ((1ull << G) - 1ull);
-            n_ties += __popcll(tie_mask[c]);
-        }
-        int pick = 0;
-        if (n_ties > 1) {
-            uint32_t r = 0;
-            if (j == 0) r = mt_below(mt_key, &mt_pos, static_cast<uint32_t>(n_ties), &words);
-            pick = static_cast<int>(__shfl(r, 0, G));
-        } else if (n_ties == 0) {  // NaN scores: the reference would raise; flag and take slot 0
-            if (j == 0) atomicOr(error_flag, 1);
-            tie_mask[0] = 1ull;
-        }
-        int sel_visits = 0, sel_child = -1, sel_loc = 0;
-        {
-            int remaining = pick;
-            bool found = false;
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                unsigned long long m = tie_mask[c];
-                const int cnt = __popcll(m);
-                if (!found && remaining < cnt) {
-                    for (int i = 0; i < remaining; ++i) m &= m - 1ull;
-                    const int bit = __ffsll(static_cast<long long>(m)) - 1;
-                    slot = c * G + bit;
-                    // the chosen lane publishes its child's links to the group with an OR-butterfly of DPP
-                    // moves (child_node is biased by 1 so that "not expanded" (-1) contributes zero bits)
-                    int pub_visits = (j == bit) ? lk[c].visits : 0;
-                    int pub_child = (j == bit) ? lk[c].child_node + 1 : 0;
-                    int pub_loc = (j == bit) ? lk[c].block_loc : 0;
-                    if constexpr (G <= 16) {
-                        // over the whole group, so that every lane ends up with the values
-                        MZ_BUTTERFLY(G, G, (pub_visits |= partner_bits<M>(pub_visits),
-                                            pub_child |= partner_bits<M>(pub_child),
-                                            pub_loc |= partner_bits<M>(pub_loc)));
-                    } else {
-                        pub_visits = __shfl(lk[c].visits, bit, G);
-                        pub_child = __shfl(lk[c].child_node, bit, G) + 1;
-                        pub_loc = __shfl(lk[c].block_loc, bit, G);
-                    }
-                    sel_visits = pub_visits;
-                    sel_child = pub_child - 1;
-                    sel_loc = pub_loc;
-                    found = true;
-                } else if (!found) {
-                    remaining -= cnt;  // (found / remaining are uniform across the group's lanes)
-                }
-            }
-        }
+        const LevelPick pick = select_level<G, CH>(acc, pbc_table, S, A, loc, N, n_children, span, mm, discount, two_player,
+                                                   mt_key, mt_pos, words, j, group_base, error_flag);
+        slot = pick.slot;
         if (j == 0) {
             acc.path_store(depth, (loc << 8) | slot);
-            if (path_ties) path_ties[static_cast<size_t>(depth) * ties_stride] = n_ties;
+            if (path_ties) path_ties[static_cast<size_t>(depth) * ties_stride] = pick.n_ties;
         }
         ++depth;
-        if (sel_child < 0) break;  // reached a node that is not expanded yet
-        if (depth > sim) {         // cannot happen on a consistent tree (only sim+1 nodes are expanded);
+        if (pick.child < 0) break;  // reached a node that is not expanded yet
+        if (depth > sim) {          // cannot happen on a consistent tree (only sim+1 nodes are expanded);
             if (j == 0) atomicOr(error_flag, 2);  // guarantees every wave leaves the loop regardless
             break;
         }
-        k = sel_child;
-        loc = sel_loc;
-        N = sel_visits;
+        k = pick.child;
+        loc = pick.loc;
+        N = pick.visits;
         n_children = A;
     }
     return Descent{depth, k, slot, loc, N};
@@ -382,8 +446,8 @@ __device__ __forceinline__ void group_softmax(const float (&logit)[CH], const bo
 // node.expand over the full action space (self_play.py:346-352, 452-466): children of node k_new.
 template <int G, int CH, typename Acc>
 __device__ __forceinline__ void write_children(const Acc& acc, int loc_new, int A, const double (&prior)[CH], int j) {
-    ChildStats* stats = acc.stats(loc_new);
-    ChildLinks* links = acc.links(loc_new);
+    const auto stats = acc.stats(loc_new);
+    const auto links = acc.links(loc_new);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int child = c * G + j;
@@ -582,8 +646,8 @@ __device__ __forceinline__ void backup(const Acc& acc, int depth, int sim, doubl
 template <int G, int CH, typename Acc>
 __device__ __forceinline__ void write_root_children(const Acc& acc, int A, int n_children, double (&prior)[CH],
                                                     const double* noise_row, double noise_frac, int j) {
-    ChildStats* stats = acc.stats(0);
-    ChildLinks* links = acc.links(0);
+    const auto stats = acc.stats(0);
+    const auto links = acc.links(0);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int child = c * G + j;

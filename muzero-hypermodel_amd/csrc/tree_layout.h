@@ -9,12 +9,15 @@
 //                  half 0; with 64-byte blocks (A <= 2) the FIRST child a node expands moves into the free second
 //                  half of that node's line instead (when the node owns its line), so that the most frequent hop of
 //                  a descent (65 % on the CartPole traces) needs no new 128-byte line.  Block (k,e) holds the A children of
-//                  expanded node k of tree e as two 16-byte-wide member arrays (struct-of-arrays
-//                  inside the block, so one lane per child reads two fully coalesced dwordx4):
-//                      ChildStats stats[A]   { f64 value_sum; f64 prior }
-//                      ChildLinks links[A]   { f32 reward; i32 visits; i32 child_node; i32 pad }
-//                  32*A bytes, padded to a multiple of 64 B (CartPole A=2: exactly one 64-B line per
-//                  descent step).  Writes of a whole slab k by expand are contiguous over (e, child).
+//                  expanded node k of tree e as A 32-byte child records (HbmChild)
+//                      HbmChild    { ChildStats { f64 value_sum; f64 prior };
+//                                    ChildLinks { f32 reward; i32 visits; i32 child_node; i32 block_loc } }
+//                  one lane per child reads its record with two dwordx4; the backup's read-modify-write of a path node
+//                  (value_sum, reward, visits) stays inside ONE 32-byte sector, the unit the memory system fetches and
+//                  writes back (round 2: as two member arrays a node update cost two sectors each way).  32*A bytes,
+//                  padded to a multiple of 64 B (CartPole A=2: exactly one 64-B block per descent step).  Trees that
+//                  live in LDS (fused kernels) keep the two members as separate 16-byte-wide arrays (conflict-free
+//                  ds_read_b128 across the lanes) and publish records.
 //   hidden pool    f32 [(S+1)][E][H]: the state of expanded node k.  The network writes slab s+1
 //                  as one contiguous [E,H] matrix; select gathers rows (k_e, e) into a batch.
 //   path           i32 [S][E]: level d of the current descent, packed (parent k << 16 | slot).
@@ -42,6 +45,14 @@ struct alignas(16) ChildLinks {
     int32_t block_loc;   // where the child's own block lives: 2 * (slab index) + (half of the line), see line_stride
 };
 
+// A child as it lives in HBM: one 32-byte sector holds everything a descent reads and a backup rewrites of it.
+struct alignas(32) HbmChild {
+    ChildStats stats;
+    ChildLinks links;
+};
+constexpr uint32_t kChildRecordBytes = 32;
+static_assert(sizeof(HbmChild) == kChildRecordBytes, "a child record is one 32-byte sector");
+
 struct alignas(16) MinMax {
     double minimum, maximum;  // MinMaxStats (self_play.py:551-568)
 };
@@ -51,7 +62,7 @@ struct TreeParams {
     int32_t chunks;          // ceil(A / 64) when A > 64, else 1
     int32_t group;           // lanes per tree: pow2 >= min(A, 64), one wavefront holds 64/group trees
     uint32_t block_stride;   // bytes per child block
-    uint32_t links_offset;   // 16 * A
+    uint32_t links_offset;   // 16 * A: where the links array of an LDS-resident block starts (HBM blocks hold records)
     uint32_t line_stride;    // HBM pool: bytes between the lines of consecutive trees in a slab.  = block_stride, or
                              // 128 when a 64-byte block shares its line with the block of its node's first-expanded
                              // child (A <= 2): the memory system fetches 128-byte lines whatever a request asks for

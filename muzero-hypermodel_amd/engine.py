@@ -620,6 +620,11 @@ class BatchedMCTS:
         self._check(self._lib.mzmcts_search_statistics(self._h, ptr(cv, c_f64_p), ptr(rv, c_f64_p)))
         return cv, rv
 
+    def set_select_queue(self, trees_per_wavefront=0):
+        """Trees each wavefront of `select` works through: 0 / 1 = one descent per lane group (default), n = a
+        wavefront-local queue of n trees (results do not depend on it; measured slower)."""
+        self._check(self._lib.mzmcts_set_select_queue(self._h, int(trees_per_wavefront)))
+
     # ---- measurement -------------------------------------------------------------------------------
     def set_profiling(self, enabled):
         self._profiling = bool(enabled)

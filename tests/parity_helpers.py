@@ -159,7 +159,7 @@ def _result_arrays(T, A, S):
 
 
 def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="cuda", temperature=1.0,
-                           record_paths=True, repeat=1, engine=None, group_width=0, fused_step=False):
+                           record_paths=True, repeat=1, engine=None, group_width=0, fused_step=False, select_queue=0):
     """Drive the HIP engine through the C ABI with injected streams.
 
     `repeat` tiles the T trees `repeat` times (env e replays stream e % T), which exercises batching:
@@ -180,6 +180,8 @@ def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="
         engine.seed(streams["seeds"] * repeat)
     if record_paths:
         engine.set_debug_ties(True)
+    if select_queue:
+        engine.set_select_queue(select_queue)   # trees per wavefront of `select` (0 = one descent per lane group)
 
     def tile(a):
         return np.concatenate([a] * repeat, axis=0)

@@ -108,6 +108,29 @@ def test_injected_traces_one_lane_per_tree(eng, oracle, name):
     assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, : int(fx["cfg_S"])])
 
 
+@pytest.mark.parametrize("name", TRACE_FILES)
+@pytest.mark.parametrize("queue", [40, 256])
+def test_injected_traces_select_queue(eng, oracle, name, queue):
+    """select with a wavefront-local queue of trees (mzmcts_set_select_queue): lane groups whose descent ended pick
+    up the next tree of their wavefront.  Every trace tiled 5x, `queue` trees per wavefront (40: a
+    ragged refill and a ragged last wavefront; 256: several refills per lane group): the same bits as the
+    reference's traces -- paths, tie lists and RNG words included -- and every copy identical."""
+    fx = load_golden(name)
+    idx = list(range(len(fx["seed"])))
+    temps = fx["temperature"].tolist()
+    got = run_injected_on_engine(eng, None, fx, idx, temperature=temps, repeat=5, select_queue=queue)
+    want = run_injected_on_oracle(oracle, fx, idx=idx, temperature=temps)
+    assert got["all_equal"]
+    assert_exact(got, want, where=f"{name} (select queue {queue}) vs oracle: ")
+    S = int(fx["cfg_S"])
+    for key in ("noise", "visits", "child_value_sum", "child_prior", "child_reward"):
+        assert np.array_equal(got[key], fx[key]), key
+    assert np.array_equal(got["sim_depth"], fx["sim_depth"])
+    assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, :S])
+    assert np.array_equal(got["sim_ties"], fx["sim_ties"][:, :, :S])
+    assert np.array_equal(got["depth_sum"], fx["sim_depth"].sum(axis=1))
+
+
 def test_injected_batching_independence(eng):
     """4096 trees = the 32 CartPole traces tiled 128x: every copy must be identical to the first."""
     fx = load_golden("g4_cartpole_traces")

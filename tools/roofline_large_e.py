@@ -14,6 +14,9 @@ from parity_helpers import make_search_config
 
 STEP = "--fused-step" in sys.argv                     # expand_backup + next select in one launch
 sys.argv = [a for a in sys.argv if a != "--fused-step"]
+QUEUE = 0                                             # --queue N: trees per wavefront of select (0 = no queue)
+if "--queue" in sys.argv:
+    i = sys.argv.index("--queue"); QUEUE = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
 log2e = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 A = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 50
@@ -24,6 +27,7 @@ eng = importlib.import_module("muzero-hypermodel_amd.engine")
 cfg = make_search_config(A, S, 1 if A == 2 else 2, 0.997, H=H)
 t0 = time.time()
 engine = eng.BatchedMCTS(cfg, E, group_width=GROUP)
+engine.set_select_queue(QUEUE)
 print(f"engine for E={E} built in {time.time()-t0:.1f}s, device pools {engine.device_bytes()/2**30:.2f} GiB", flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 value = (torch.randn(E, generator=g, device="cuda", dtype=torch.float32) * 30).double()
@@ -55,7 +59,7 @@ torch.cuda.synchronize()
 prof = engine.get_profile(reset=True)
 d = prof["select_depth_sum"] / max(prof["simulations"], 1)
 b = engine.algorithmic_bytes_per_simulation(d)
-out = {"lanes_per_tree": engine.group_width() if GROUP != 1 else 1, "E": E, "A": A, "S": S, "H": H, "mean_select_depth": d, "device_pool_GiB": engine.device_bytes() / 2**30, "kernels": {}}
+out = {"lanes_per_tree": engine.group_width() if GROUP != 1 else 1, "select_queue_trees": QUEUE, "E": E, "A": A, "S": S, "H": H, "mean_select_depth": d, "device_pool_GiB": engine.device_bytes() / 2**30, "kernels": {}}
 for name, ms, n, per in (("select", "select_ms", "select_launches", b["select"]), ("expand_backup", "expand_backup_ms", "expand_backup_launches", b["expand_backup"])):
     us = 1e3 * prof[ms] / prof[n]
     out["kernels"][name] = {"avg_us": us, "launches": prof[n], "algorithmic_bytes_per_launch": per * E,
