@@ -415,6 +415,18 @@ int mzmcts_get_profile(mzmcts_engine *engine, mzmcts_profile *out, int32_t reset
 /* Bytes of device memory the engine's pools occupy (node blocks, hidden pool, RNG, paths). */
 int64_t mzmcts_device_bytes(const mzmcts_engine *engine);
 
+/* ---- exploration noise on the device (numpy.random.dirichlet, self_play.py:468-477) -------------------
+ * The legacy gamma sampler goes through libm's log and pow; the library carries glibc's algorithms and tables
+ * (csrc/glibc_libm.h) so that device-drawn noise is the reference's to the last bit.  Two blocking self-checks
+ * (host arrays in and out):
+ *   mzmcts_device_libm       log_out[i] = log(x[i]), pow_out[i] = pow(x[i], y[i]) computed on the GPU, for comparison
+ *                            with the host's libm (x >= 0 finite, y > 0);
+ *   mzmcts_device_dirichlet  stream s = numpy.random.seed(seeds[s]) followed by `draws` x dirichlet([alpha] * k) on the
+ *                            GPU, 0 < alpha <= 1: out f64[n_streams][draws][k], words_out[s] = 32-bit words consumed. */
+int mzmcts_device_libm(const double *x, const double *y, int64_t n, double *log_out, double *pow_out);
+int mzmcts_device_dirichlet(const uint32_t *seeds, int32_t n_streams, double alpha, int32_t k, int32_t draws,
+                            double *out, uint32_t *words_out);
+
 /* ---- stand-alone host RNG stream (numpy legacy RandomState clone) ----------------------------
  * The same generator the engine uses per env, exposed for host logic that has no engine
  * (SelfPlay.select_opponent_action's numpy.random.choice, self_play.py:217) and for CPU tests. */

@@ -158,6 +158,9 @@ PROTOTYPES = {
     "mzmcts_rng_choice_priorities": (ctypes.c_int32, [c_void, c_f32_p, ctypes.c_int32, c_f32_p]),
     "mzmcts_rng_choice_p": (ctypes.c_int32, [c_void, c_f64_p, ctypes.c_int32]),
     "mzmcts_rng_dirichlet": (None, [c_void, ctypes.c_double, ctypes.c_int32, c_f64_p]),
+    "mzmcts_device_libm": (ctypes.c_int, [c_f64_p, c_f64_p, ctypes.c_int64, c_f64_p, c_f64_p]),
+    "mzmcts_device_dirichlet": (ctypes.c_int, [c_u32_p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
+                                               c_f64_p, c_u32_p]),
     "mzmcts_rng_export": (None, [c_void, c_u32_p, c_i32_p, c_i32_p, c_f64_p]),
     "mzmcts_rng_import": (None, [c_void, c_u32_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     "mzmcts_rng_select_action": (ctypes.c_int32, [c_void, c_i32_p, ctypes.c_int32, ctypes.c_double]),

@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
 SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "mzmcts_moves.hip", "mzmcts_rng.hip", "mzhist.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip", "board_conv.hip"]
-HEADERS = ["engine_host.h", "np_legacy_rng.h", "tree_layout.h", "tree_device.h", "fc_net_device.h", "narrow_device.h", "kernel_common.h", "env_layout.h", os.path.join("..", "..", "include", "mzmcts.h"),
+HEADERS = ["engine_host.h", "np_legacy_rng.h", "glibc_libm.h", "glibc_libm_tables.inc", "tree_layout.h", "tree_device.h", "fc_net_device.h", "narrow_device.h", "kernel_common.h", "env_layout.h", os.path.join("..", "..", "include", "mzmcts.h"),
            os.path.join("..", "..", "include", "mzenv.h"), os.path.join("..", "..", "include", "mzreplay.h"), os.path.join("..", "..", "include", "mzhist.h")]
 
 # -fno-slp-vectorize: packing adjacent scalar f32 FMAs into v_pk_fma_f32 costs more in register shuffles

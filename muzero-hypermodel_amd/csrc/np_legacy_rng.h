@@ -9,11 +9,16 @@
 //     kernel breaks UCB ties on-device);
 //   * everything that needs libm transcendentals (gamma / Dirichlet) or visit-count powers
 //     (select_action) runs on the host against the same glibc libm numpy itself calls, on a host
-//     mirror of the stream that is kept in step with the device copy by word counts.
+//     mirror of the stream that is kept in step with the device copy by word counts;
+//   * the Dirichlet draw for shape <= 1 (every reference config: root_dirichlet_alpha 0.1 ... 0.3) ALSO runs on the
+//     device (DeviceStream below, on glibc's log / pow restated in glibc_libm.h), so that a batch of moves needs
+//     no pre-drawn noise from the host.
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+
+#include "glibc_libm.h"
 
 #if defined(__HIPCC__)
 #define MZ_HD __host__ __device__
@@ -92,6 +97,48 @@ MZ_HD inline uint32_t mt_below(uint32_t* key, int32_t* pos, uint32_t n, uint32_t
     } while (v > top);
     return v;
 }
+
+// ---- the legacy distributions of the exploration noise over caller-provided MT19937 storage ------------
+// (usable on the device: log / pow are glibc's, restated; the same code runs on the host in the tests)
+struct DeviceStream {
+    uint32_t* key;
+    int32_t pos;
+    uint32_t words;   // 32-bit words drawn through this object
+    MZ_HD double uniform() {  // legacy_double: 53 random bits from two words
+        const int32_t a = static_cast<int32_t>(mt_next(key, &pos) >> 5);
+        const int32_t b = static_cast<int32_t>(mt_next(key, &pos) >> 6);
+        words += 2u;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    MZ_HD double exponential() { return -libm::glibc_log(1.0 - uniform()); }
+    // legacy_standard_gamma for shape <= 1 (the shape > 1 branch needs legacy_gauss and its cached value: host only)
+    MZ_HD double gamma_le1(double shape) {
+        if (shape == 1.0) return exponential();
+        if (shape == 0.0) return 0.0;
+        for (;;) {
+            const double u = uniform();
+            const double v = exponential();
+            if (u <= 1.0 - shape) {
+                const double x = libm::glibc_pow(u, 1. / shape);
+                if (x <= v) return x;
+            } else {
+                const double y = -libm::glibc_log((1 - u) / shape);
+                const double x = libm::glibc_pow(1.0 - shape + shape * y, 1. / shape);
+                if (x <= (v + y)) return x;
+            }
+        }
+    }
+    // RandomState.dirichlet([alpha] * k), alpha <= 1
+    MZ_HD void dirichlet(double alpha, int k, double* out) {
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) {
+            out[j] = gamma_le1(alpha);
+            acc = acc + out[j];
+        }
+        const double inv = 1 / acc;
+        for (int j = 0; j < k; ++j) out[j] = out[j] * inv;
+    }
+};
 
 // ---- host stream: the full legacy distribution set the path needs -----------------------------
 struct HostStream {
