@@ -82,6 +82,9 @@ def parse_args(argv=None):
                     help="the K timed steps are repeated until the timed region lasts at least this long")
     ap.add_argument("--bcast-every", type=int, default=50, help="weight broadcast period in steps (N>1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--device-noise", action="store_true",
+                    help="draw the exploration noise on the GPU instead of on the host mirrors of the RNG streams "
+                         "(lock-step workloads; the same rows to the last bit)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="budget of each cpu_baseline leg, 1 core and all cores (0 = skip)")
@@ -243,7 +246,8 @@ class Workload:
         group = args.group if args.group else (16 if self.fused else 0)
         actor_mod = pkg("actor")
         self.actor = actor_mod.SearchActor(self.config, weights, self.E, rank=rank, device=device,
-                                           use_graph=not args.no_graph, group_width=group, fused_fc=self.fused)
+                                           use_graph=not args.no_graph, group_width=group, fused_fc=self.fused,
+                                           device_noise=args.device_noise)
         self.engine, self.model = self.actor.engine, self.actor.model
         self.engine.fused_hidden_in_lds = not args.hidden_in_hbm
         rs = np.random.RandomState(123 + rank)

@@ -423,6 +423,13 @@ int64_t mzmcts_device_bytes(const mzmcts_engine *engine);
  *                            with the host's libm (x >= 0 finite, y > 0);
  *   mzmcts_device_dirichlet  stream s = numpy.random.seed(seeds[s]) followed by `draws` x dirichlet([alpha] * k) on the
  *                            GPU, 0 < alpha <= 1: out f64[n_streams][draws][k], words_out[s] = 32-bit words consumed. */
+/* Who draws add_exploration_noise's Dirichlet row of a search: 0 (default) = the host mirror of each stream, inside
+ * mzmcts_begin_search (rows returned in noise_out and uploaded); 1 = the GPU, on the device copy of each stream, queued
+ * by mzmcts_begin_search right behind its upload (no host work per env; 0 < root_dirichlet_alpha <= 1).  Either way
+ * the rows, the search and the stream afterwards are the same to the last bit.  With 1, noise_out is zeros and the
+ * rows reach the host with mzmcts_readout: mzmcts_get_noise copies them (f64[E][A], by root child slot). */
+int mzmcts_set_device_noise(mzmcts_engine *engine, int32_t enabled);
+int mzmcts_get_noise(mzmcts_engine *engine, double *noise_out);
 int mzmcts_device_libm(const double *x, const double *y, int64_t n, double *log_out, double *pow_out);
 int mzmcts_device_dirichlet(const uint32_t *seeds, int32_t n_streams, double alpha, int32_t k, int32_t draws,
                             double *out, uint32_t *words_out);

@@ -158,6 +158,8 @@ PROTOTYPES = {
     "mzmcts_rng_choice_priorities": (ctypes.c_int32, [c_void, c_f32_p, ctypes.c_int32, c_f32_p]),
     "mzmcts_rng_choice_p": (ctypes.c_int32, [c_void, c_f64_p, ctypes.c_int32]),
     "mzmcts_rng_dirichlet": (None, [c_void, ctypes.c_double, ctypes.c_int32, c_f64_p]),
+    "mzmcts_set_device_noise": (ctypes.c_int, [c_void, ctypes.c_int32]),
+    "mzmcts_get_noise": (ctypes.c_int, [c_void, c_f64_p]),
     "mzmcts_device_libm": (ctypes.c_int, [c_f64_p, c_f64_p, ctypes.c_int64, c_f64_p, c_f64_p]),
     "mzmcts_device_dirichlet": (ctypes.c_int, [c_u32_p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
                                                c_f64_p, c_u32_p]),

@@ -51,7 +51,7 @@ class SearchActor:
     by the caller as observation / legal-action batches, e.g. bench.py's synthetic rollouts)."""
 
     def __init__(self, config, weights, envs_per_rank, rank=0, device=None, use_graph=True, group_width=0,
-                 fused_fc=False):
+                 fused_fc=False, device_noise=False):
         self.config = config
         self.rank = rank
         self.device = torch.device(device if device is not None else "cuda")
@@ -66,6 +66,9 @@ class SearchActor:
         if fused_fc:
             # the fused kernel reads the same flat buffer the RCCL broadcast lands in
             self.engine.configure_fused_fc(self.model, self.flat)
+        if device_noise:
+            self.engine.use_device_noise()   # Dirichlet rows drawn on the GPU: the same rows as the host mirrors', no
+                                             # host work per env (measured equal within noise on the lock-step configs)
         self.weight_version = 0
 
     def refresh_weights(self, src=0):

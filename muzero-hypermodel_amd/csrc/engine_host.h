@@ -53,6 +53,7 @@ hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const F
                                   const LaunchTiming* timing);
 hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, int queue_trees,
                          hipStream_t stream, const LaunchTiming* timing);
+hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_t stream);
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
                                         hipStream_t stream);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -249,6 +250,9 @@ struct mzmcts_engine {
 
     // profiling
     bool profiling = false;
+    bool device_noise = false;       // mzmcts_set_device_noise: exploration noise drawn by root_noise_kernel
+    bool noise_on_device = false;    // ... and it was, for the search in progress (readout fetches rows + word counts)
+    uint32_t* h_noise_words = nullptr;
     int select_queue_trees = 0;      // mzmcts_set_select_queue: 0 = one descent per lane group
     std::vector<EventPair> events;
     size_t events_used = 0;

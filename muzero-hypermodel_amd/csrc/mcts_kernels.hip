@@ -523,6 +523,37 @@ __global__ __launch_bounds__(kThreads) void expand_backup_select_kernel(TreePara
     select_tree<G, CH, FUSE_GATHER>(p, sim + 1, pbc_table, e, j, group_base, n_root, mm, mt_pos, hidden_out, action_out);
 }
 
+// add_exploration_noise's draw (self_play.py:468-477: numpy.random.dirichlet([alpha] * len(actions))) on every
+// tree's OWN stream, on the device: the legacy gamma sampler over glibc's log / pow (np_legacy_rng.h DeviceStream,
+// glibc_libm.h), one thread per tree.  First steps over the words the host mirror consumed since the device copy last
+// moved (rng_skip, zeroed here so that the search's own reset does not skip them again).  The rows go where a host
+// draw would have been uploaded; expand_roots / the whole-move kernels read them from there.
+constexpr int kNoiseWindow = 96;
+__global__ __launch_bounds__(kThreads) void root_noise_kernel(TreeParams p, uint32_t* __restrict__ rng_skip) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const int n = p.root_children[e];
+    double* row = p.noise_rows + static_cast<size_t>(e) * p.A;
+    for (int i = 0; i < p.A; ++i) row[i] = 0.0;
+    p.noise_words[e] = 0u;
+    if (n == 0) return;  // inactive: the stream is left alone
+    uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
+    int32_t pos = p.mt_pos[e];
+    const uint32_t skip = rng_skip ? rng_skip[e] : 0u;
+    for (uint32_t i = 0; i < skip; ++i) (void)mt_next(key, &pos);
+    if (rng_skip) rng_skip[e] = 0u;
+    // the words the draw is likely to consume, staged in LDS with every load in flight (a gamma variate takes >= 4
+    // words; read one by one out of global memory each is a dependent round trip)
+    __shared__ uint32_t window[kThreads][kNoiseWindow + 1];
+    const int ahead = (kMtN - pos < kNoiseWindow) ? kMtN - pos : kNoiseWindow;
+#pragma unroll 8
+    for (int i = 0; i < ahead; ++i) window[threadIdx.x][i] = key[pos + i];
+    DeviceStream stream{key, pos, 0u, window[threadIdx.x], pos, pos + (ahead > 0 ? ahead : 0)};
+    stream.dirichlet(p.noise_alpha, n, row);
+    p.mt_pos[e] = stream.pos;
+    p.noise_words[e] = stream.words;
+}
+
 // numpy.random.seed(seeds[e]) for every stream, on the device copy.
 __global__ __launch_bounds__(256) void seed_streams_kernel(uint32_t* __restrict__ keys, int32_t* __restrict__ pos,
                                                            const uint32_t* __restrict__ seeds, int E) {
@@ -867,6 +898,11 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
         err = hipGetLastError();
     }
     return err;
+}
+
+hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_t stream) {
+    root_noise_kernel<<<dim3((p.E + kThreads - 1) / kThreads), dim3(kThreads), 0, stream>>>(p, rng_skip);
+    return hipGetLastError();
 }
 
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,

@@ -70,6 +70,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     p.line_stride = p.block_stride == 64u ? 128u : p.block_stride;
     p.discount = c->discount;
     p.noise_frac = c->root_exploration_fraction;
+    p.noise_alpha = c->root_dirichlet_alpha;
 
     int rc = 0;
     auto cleanup_on = [&](int code) {
@@ -110,6 +111,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         p.root_to_play = reinterpret_cast<int32_t*>(eng->d_upload + o_to_play);
         eng->d_skip = reinterpret_cast<uint32_t*>(eng->d_upload + o_skip);
         eng->d_noise = reinterpret_cast<double*>(eng->d_upload + o_noise);
+        p.noise_rows = eng->d_noise;
         eng->h_legal = reinterpret_cast<int32_t*>(eng->h_upload + o_legal);
         eng->h_nlegal = reinterpret_cast<int32_t*>(eng->h_upload + o_nlegal);
         eng->h_to_play = reinterpret_cast<int32_t*>(eng->h_upload + o_to_play);
@@ -123,7 +125,8 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         const size_t o_pred = o_ds + sizeof(int64_t) * E;
         const size_t o_md = o_pred + sizeof(float) * E;
         const size_t o_tw = o_md + sizeof(int32_t) * E;
-        const size_t o_err = o_tw + sizeof(uint32_t) * E;
+        const size_t o_nw = o_tw + sizeof(uint32_t) * E;
+        const size_t o_err = o_nw + sizeof(uint32_t) * E;
         eng->download_bytes = o_err + sizeof(int32_t) * 4;
         if ((rc = dev_alloc(eng, &eng->d_download, eng->download_bytes))) return cleanup_on(rc);
         if ((rc = pinned_alloc(eng, &eng->h_download, eng->download_bytes))) return cleanup_on(rc);
@@ -133,6 +136,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         p.root_predicted = reinterpret_cast<float*>(eng->d_download + o_pred);
         p.max_depth = reinterpret_cast<int32_t*>(eng->d_download + o_md);
         p.tie_words = reinterpret_cast<uint32_t*>(eng->d_download + o_tw);
+        p.noise_words = reinterpret_cast<uint32_t*>(eng->d_download + o_nw);
         p.error_flag = reinterpret_cast<int32_t*>(eng->d_download + o_err);
         eng->h_root_value_sum = reinterpret_cast<double*>(eng->h_download + o_rvs);
         eng->h_min_max = reinterpret_cast<mz::MinMax*>(eng->h_download + o_mm);
@@ -140,6 +144,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         eng->h_root_predicted = reinterpret_cast<float*>(eng->h_download + o_pred);
         eng->h_max_depth = reinterpret_cast<int32_t*>(eng->h_download + o_md);
         eng->h_tie_words = reinterpret_cast<uint32_t*>(eng->h_download + o_tw);
+        eng->h_noise_words = reinterpret_cast<uint32_t*>(eng->h_download + o_nw);
         eng->h_error_flag = reinterpret_cast<int32_t*>(eng->h_download + o_err);
     }
     if ((rc = dev_alloc(eng, &p.mt_key, static_cast<size_t>(E) * mz::kMtN))) return cleanup_on(rc);
@@ -264,6 +269,7 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
     std::memcpy(eng->h_nlegal, num_legal, sizeof(int32_t) * E);
     std::memcpy(eng->h_to_play, to_play, sizeof(int32_t) * E);
     const double alpha = eng->cfg.root_dirichlet_alpha;
+    const bool on_device = add_noise && eng->device_noise;   // root_noise_kernel draws the rows, below
     eng->for_each_env([&](int lo, int hi) {
         for (int e = lo; e < hi; ++e) {
             const int n = eng->h_nlegal[e];
@@ -273,7 +279,7 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
                 eng->h_skip[e] = 0;  // inactive: the stream is left alone, pending lag is kept
                 continue;
             }
-            if (add_noise) {
+            if (add_noise && !on_device) {
                 mz::HostStream& s = eng->streams[e];
                 const uint64_t before = s.words;
                 s.dirichlet(alpha, n, row);
@@ -286,8 +292,11 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
     const double t_dirichlet = trace ? now() : 0.0;
     if (noise_out) std::memcpy(noise_out, eng->h_noise, sizeof(double) * static_cast<size_t>(E) * A);
     eng->noise_this_search = add_noise != 0;
-    MZ_HIP(eng, hipMemcpyAsync(eng->d_upload, eng->h_upload, add_noise ? eng->upload_bytes : eng->upload_bytes_no_noise,
+    MZ_HIP(eng, hipMemcpyAsync(eng->d_upload, eng->h_upload,
+                               (add_noise && !on_device) ? eng->upload_bytes : eng->upload_bytes_no_noise,
                                hipMemcpyHostToDevice, stream));
+    if (on_device) MZ_HIP(eng, mz::launch_root_noise(eng->p, eng->d_skip, stream));
+    eng->noise_on_device = on_device;
     if (trace)
         std::fprintf(stderr, "[mzmcts] begin_search E=%d: host prep+dirichlet %.1f us, memcpy+enqueue %.1f us\n", E,
                      t_dirichlet - t_start, now() - t_dirichlet);
@@ -460,6 +469,9 @@ static int enqueue_readout_copies(mzmcts_engine* eng, hipStream_t stream) {
     const mz::TreeParams& p = eng->p;
     MZ_HIP(eng, hipMemcpyAsync(eng->h_slab0, p.blocks, static_cast<size_t>(p.E) * p.line_stride, hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipMemcpyAsync(eng->h_download, eng->d_download, eng->download_bytes, hipMemcpyDeviceToHost, stream));
+    if (eng->noise_on_device)   // the rows the device drew (what mzmcts_begin_search's noise_out holds for a host draw)
+        MZ_HIP(eng, hipMemcpyAsync(eng->h_noise, eng->d_noise, sizeof(double) * static_cast<size_t>(p.E) * p.A,
+                                   hipMemcpyDeviceToHost, stream));
     return MZMCTS_OK;
 }
 
@@ -521,7 +533,8 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
             eng->last_root_visits[e] = is_active ? sims : 0;
             if (is_active) {
                 // the tie-breaks ran on the device copy of the stream: bring the host mirror level (once)
-                if (first) eng->streams[e].skip(eng->h_tie_words[e]);
+                // (and, when the device drew this search's exploration noise, the Dirichlet draw before them)
+                if (first) eng->streams[e].skip((eng->noise_on_device ? eng->h_noise_words[e] : 0u) + eng->h_tie_words[e]);
                 local_depth += eng->h_depth_sum[e];
                 ++local_active;
             }
@@ -934,6 +947,24 @@ int mzmcts_debug_read_stamps(unsigned long long* out, int32_t reset) {
 int mzmcts_set_profiling(mzmcts_engine* eng, int32_t enabled) {
     if (!eng) return MZMCTS_ERR_INVALID;
     eng->profiling = enabled != 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_set_device_noise(mzmcts_engine* eng, int32_t enabled) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    if (enabled && !(eng->cfg.root_dirichlet_alpha > 0.0 && eng->cfg.root_dirichlet_alpha <= 1.0))
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_set_device_noise: the device draws Dirichlet noise for 0 < "
+                                             "root_dirichlet_alpha <= 1 only (larger shapes go through legacy_gauss "
+                                             "and its cached value: host)");
+    eng->device_noise = enabled != 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_get_noise(mzmcts_engine* eng, double* noise_out) {
+    if (!eng || !noise_out) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_get_noise: null argument");
+    if (eng->noise_on_device && !eng->have_readout)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_get_noise: device-drawn rows reach the host with mzmcts_readout");
+    std::memcpy(noise_out, eng->h_noise, sizeof(double) * static_cast<size_t>(eng->p.E) * eng->p.A);
     return MZMCTS_OK;
 }
 

@@ -23,7 +23,7 @@ __global__ void device_dirichlet_kernel(const uint32_t* __restrict__ seeds, int 
     uint32_t* key = keys + static_cast<size_t>(s) * mz::kMtN;
     int32_t pos;
     mz::mt_seed(key, &pos, seeds[s]);
-    mz::DeviceStream stream{key, pos, 0u};
+    mz::DeviceStream stream{key, pos, 0u, nullptr, 0, 0};
     for (int d = 0; d < draws; ++d) stream.dirichlet(alpha, k, out + (static_cast<size_t>(s) * draws + d) * k);
     words[s] = stream.words;
 }

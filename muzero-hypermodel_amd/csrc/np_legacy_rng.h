@@ -104,9 +104,22 @@ struct DeviceStream {
     uint32_t* key;
     int32_t pos;
     uint32_t words;   // 32-bit words drawn through this object
+    // optional copy of key[win_lo, win_hi) in fast memory (the device kernel stages the words a draw is likely to
+    // consume in LDS with all loads in flight, instead of one dependent global load per word)
+    const uint32_t* window = nullptr;
+    int32_t win_lo = 0, win_hi = 0;
+    MZ_HD uint32_t next_word() {
+        if (pos >= win_lo && pos < win_hi) {
+            const uint32_t y = window[pos - win_lo];
+            ++pos;
+            return mt_temper(y);
+        }
+        if (pos >= kMtN) win_hi = 0;  // the regeneration rewrites the block the window was copied from
+        return mt_next(key, &pos);
+    }
     MZ_HD double uniform() {  // legacy_double: 53 random bits from two words
-        const int32_t a = static_cast<int32_t>(mt_next(key, &pos) >> 5);
-        const int32_t b = static_cast<int32_t>(mt_next(key, &pos) >> 6);
+        const int32_t a = static_cast<int32_t>(next_word() >> 5);
+        const int32_t b = static_cast<int32_t>(next_word() >> 6);
         words += 2u;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }

@@ -70,6 +70,9 @@ struct TreeParams {
     int32_t* leaf_loc;       // [E] block location select chose for the node the coming expand_backup creates
     double discount;
     double noise_frac;
+    double noise_alpha;      // config.root_dirichlet_alpha (device-drawn exploration noise, root_noise_kernel)
+    double* noise_rows;      // [E][A] Dirichlet rows of the current search when the device draws them
+    uint32_t* noise_words;   // [E] RNG words that draw consumed (the host mirror steps over them at readout)
     // pools
     uint8_t* blocks;
     float* hidden;

@@ -74,6 +74,7 @@ class BatchedMCTS:
         # lock-step loop: expand_backup + next select in one launch (mzmcts_expand_backup_select).  Bit-identical and one
         # launch fewer per simulation, but not faster where measured: off by default
         self.fused_step = False
+        self._device_noise = False
 
         with torch.cuda.device(self.device):
             self.pool = torch.empty((self.S + 1, self.E, self.H), dtype=torch.float32, device=self.device)
@@ -596,7 +597,23 @@ class BatchedMCTS:
 
     def readout(self):
         self._check(self._lib.mzmcts_readout(self._h, ctypes.byref(self._stats_struct), self._stream()))
+        if self._device_noise:          # the rows the GPU drew for this search (a host draw fills self.noise up front)
+            self._check(self._lib.mzmcts_get_noise(self._h, self._p_noise))
         return self.stats
+
+    def use_device_noise(self):
+        """Exploration noise on the GPU whenever the config allows it (0 < root_dirichlet_alpha <= 1, every reference
+        game); returns whether it is on."""
+        if 0.0 < float(self.config.root_dirichlet_alpha) <= 1.0:
+            self.set_device_noise(True)
+        return self._device_noise
+
+    def set_device_noise(self, enabled=True):
+        """Draw the exploration noise (numpy.random.dirichlet, reference self_play.py:468-477) on the GPU instead of
+        on the host mirrors of the RNG streams: same rows, same streams, no host work per env and move.  `self.noise`
+        then holds a search's rows after its readout()."""
+        self._check(self._lib.mzmcts_set_device_noise(self._h, 1 if enabled else 0))
+        self._device_noise = bool(enabled)
 
     def sample_actions(self, temperature):
         """SelfPlay.select_action per env on its own RNG stream; returns (actions, slots)."""

@@ -159,7 +159,8 @@ def _result_arrays(T, A, S):
 
 
 def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="cuda", temperature=1.0,
-                           record_paths=True, repeat=1, engine=None, group_width=0, fused_step=False, select_queue=0):
+                           record_paths=True, repeat=1, engine=None, group_width=0, fused_step=False, select_queue=0,
+                           device_noise=False):
     """Drive the HIP engine through the C ABI with injected streams.
 
     `repeat` tiles the T trees `repeat` times (env e replays stream e % T), which exercises batching:
@@ -180,6 +181,8 @@ def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="
         engine.seed(streams["seeds"] * repeat)
     if record_paths:
         engine.set_debug_ties(True)
+    if device_noise:
+        engine.set_device_noise(True)            # the GPU draws the Dirichlet rows (they reach the host at readout)
     if select_queue:
         engine.set_select_queue(select_queue)   # trees per wavefront of `select` (0 = one descent per lane group)
 
@@ -204,7 +207,7 @@ def run_injected_on_engine(engine_mod, config, fx_or_streams, idx=None, device="
         else:
             engine.expand_backup_injected(value[:, s], reward[:, s], priors[:, s, :])
     st = engine.readout()
-    out["noise"][:] = noise
+    out["noise"][:] = engine.noise if device_noise else noise
     for key in ("visits", "child_value_sum", "child_prior", "child_reward", "root_value_sum", "root_visits",
                 "max_tree_depth", "min_max"):
         out[key][:] = st[key]
