@@ -48,6 +48,16 @@ class MzProfile(ctypes.Structure):
                 ("step_ms", ctypes.c_double), ("step_launches", ctypes.c_int64)]
 
 
+class MzTrainLossArgs(ctypes.Structure):
+    """include/mztrain.h mztrain_loss_args: raw device pointers + sizes of one training step's loss."""
+    _fields_ = [(name, ctypes.c_void_p) for name in ("value_logits", "reward_logits", "policy_logits", "target_value",
+                                                     "target_reward", "target_policy", "gradient_scale", "weight")] + \
+               [("batch", ctypes.c_int32), ("steps", ctypes.c_int32), ("support_size", ctypes.c_int32),
+                ("actions", ctypes.c_int32), ("value_loss_weight", ctypes.c_float), ("per_alpha", ctypes.c_float)] + \
+               [(name, ctypes.c_void_p) for name in ("sample_loss", "head_sums", "priorities", "grad_value", "grad_reward",
+                                                     "grad_policy")]
+
+
 class MzFcDesc(ctypes.Structure):
     _fields_ = [("observation_floats", ctypes.c_int32), ("encoding_size", ctypes.c_int32),
                 ("n_hidden", ctypes.c_int32 * 5), ("hidden", (ctypes.c_int32 * 3) * 5)]
@@ -123,6 +133,7 @@ PROTOTYPES = {
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
     "mzenv_advance": (ctypes.c_int, [c_void] * 10),
+    "mztrain_unroll_loss": (ctypes.c_int, [ctypes.POINTER(MzTrainLossArgs), c_void]),
     "mzhist_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(c_void)]),
     "mzhist_destroy": (None, [c_void]),
     "mzhist_last_error": (ctypes.c_char_p, [c_void]),

@@ -8,6 +8,7 @@ leave through `publish` into the flat buffer the actors alias (weights.FlatWeigh
 instead of a state_dict through shared storage.
 """
 import copy
+import ctypes
 import time
 
 import numpy
@@ -24,7 +25,53 @@ def _scale_gradient(tensor, divisor):
     return tensor
 
 
+class _UnrollLoss(torch.autograd.Function):
+    """The loss of one training step over all unrolled positions as ONE HIP launch (include/mztrain.h
+    mztrain_unroll_loss, csrc/trainer_kernels.hip): two-hot value / reward targets, the three cross-entropies per step,
+    their sums over the steps in the reference's order, the per-sample total, the new PER priorities, and -- kept for
+    backward -- the gradient of the per-sample total with respect to every logit (gradient scales folded in).
+    Forward returns (per-sample loss [B], per-sample head sums [3, B], priorities [B, K+1]); only the first is
+    differentiable.  CUDA tensors only: on the CPU the trainer keeps the torch expression."""
+
+    @staticmethod
+    def forward(ctx, value_logits, reward_logits, policy_logits, batch, support_size, value_loss_weight, per_alpha):
+        from . import _native
+        lib = _native.load()      # raises when the HIP library is missing: no silent fallback on a GPU box
+        steps, size, full = value_logits.shape
+        actions = policy_logits.shape[2]
+        assert full == 2 * support_size + 1 and reward_logits.shape == value_logits.shape
+        v, r, p = (t.detach().contiguous().float() for t in (value_logits, reward_logits, policy_logits))
+        tv, tr, tp, gs = (batch[key].contiguous() for key in ("values", "rewards", "policies", "gradient_scales"))
+        weight = batch["weights"].contiguous() if batch["weights"] is not None else None
+        dev = v.device
+        sample_loss = torch.empty(size, device=dev)
+        head_sums = torch.empty((3, size), device=dev)
+        priorities = torch.empty((size, steps), device=dev)
+        grads = (torch.empty_like(v), torch.empty_like(r), torch.empty_like(p))
+        args = _native.MzTrainLossArgs(
+            value_logits=v.data_ptr(), reward_logits=r.data_ptr(), policy_logits=p.data_ptr(), target_value=tv.data_ptr(),
+            target_reward=tr.data_ptr(), target_policy=tp.data_ptr(), gradient_scale=gs.data_ptr(),
+            weight=weight.data_ptr() if weight is not None else None, batch=size, steps=steps, support_size=support_size,
+            actions=actions, value_loss_weight=float(value_loss_weight), per_alpha=float(per_alpha),
+            sample_loss=sample_loss.data_ptr(), head_sums=head_sums.data_ptr(), priorities=priorities.data_ptr(),
+            grad_value=grads[0].data_ptr(), grad_reward=grads[1].data_ptr(), grad_policy=grads[2].data_ptr())
+        rc = lib.mztrain_unroll_loss(ctypes.byref(args), torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mztrain_unroll_loss failed ({rc})")
+        ctx.save_for_backward(*grads)
+        ctx.mark_non_differentiable(head_sums, priorities)
+        return sample_loss, head_sums, priorities
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_sums, _grad_priorities):
+        g = grad_loss.reshape(1, -1, 1)
+        gv, gr, gp = ctx.saved_tensors
+        return gv * g, gr * g, gp * g, None, None, None, None
+
+
 class Trainer:
+    native_loss = True      # on the GPU: the loss of a step as one HIP launch (False: the torch expression, for timing)
+
     def __init__(self, initial_checkpoint, config, device=None):
         self.config = config
         numpy.random.seed(self.config.seed)
@@ -111,11 +158,14 @@ class Trainer:
     def update_weights(self, batch):
         cfg = self.config
         b = self._batch_on_device(batch)
+        steps = self._unroll(b["observations"], b["actions"])
+        if b["values"].is_cuda and self.native_loss:
+            return self._step_native(b, steps)
         value_targets = models.scalar_to_support(b["values"], cfg.support_size)
         reward_targets = models.scalar_to_support(b["rewards"], cfg.support_size)
         priorities = torch.zeros_like(b["values"])
         sums = {"value": 0, "reward": 0, "policy": 0}
-        for k, (value, reward, policy_logits) in enumerate(self._unroll(b["observations"], b["actions"])):
+        for k, (value, reward, policy_logits) in enumerate(steps):
             per_head = dict(zip(("value", "reward", "policy"), self.loss_function(
                 value.squeeze(-1), reward.squeeze(-1), policy_logits, value_targets[:, k], reward_targets[:, k],
                 b["policies"][:, k])))
@@ -139,6 +189,24 @@ class Trainer:
         self.training_step += 1
         return (priorities.detach().cpu().numpy(), loss.item(), sums["value"].mean().item(),
                 sums["reward"].mean().item(), sums["policy"].mean().item())
+
+    def _step_native(self, b, steps):
+        """The same step with everything between the network's outputs and `loss.mean()` in one HIP launch
+        (_UnrollLoss): the logits of all unrolled positions are stacked step-major, the kernel returns the
+        per-sample loss and keeps its gradient for backward."""
+        cfg = self.config
+        value = torch.stack([s[0] for s in steps])
+        reward = torch.stack([s[1] for s in steps])
+        policy = torch.stack([s[2] for s in steps])
+        sample_loss, head_sums, priorities = _UnrollLoss.apply(value, reward, policy, b, cfg.support_size,
+                                                               cfg.value_loss_weight, cfg.PER_alpha)
+        loss = sample_loss.mean()
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        self.training_step += 1
+        report = torch.cat([loss.detach().reshape(1), head_sums.mean(dim=1)]).tolist()     # one device-to-host copy
+        return (priorities.cpu().numpy(), report[0], report[1], report[2], report[3])
 
     def update_lr(self):
         lr = self.config.lr_init * self.config.lr_decay_rate ** (self.training_step / self.config.lr_decay_steps)

@@ -1,0 +1,94 @@
+"""csrc/trainer_kernels.hip (include/mztrain.h): the loss of a training step over all unrolled positions in one HIP
+launch, against the reference's torch expression (trainer.py:176-215, 271-291; models.scalar_to_support,
+models.py:665-685) -- values, new priorities, and the gradient that reaches every logit."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(pkg):
+    return (importlib.import_module("muzero-hypermodel_amd.trainer"), importlib.import_module("muzero-hypermodel_amd.models"))
+
+
+def torch_reference(trainer_mod, models, value, reward, policy, b, support, vw, alpha):
+    """The CPU branch of Trainer.update_weights on given logits (lists of per-step tensors that require grad)."""
+    value_targets = models.scalar_to_support(b["values"], support)
+    reward_targets = models.scalar_to_support(b["rewards"], support)
+    priorities = torch.zeros_like(b["values"])
+    sums = {"value": 0, "reward": 0, "policy": 0}
+    for k in range(len(value)):
+        per_head = dict(zip(("value", "reward", "policy"), trainer_mod.Trainer.loss_function(
+            value[k], reward[k], policy[k], value_targets[:, k], reward_targets[:, k], b["policies"][:, k])))
+        if k == 0:
+            del per_head["reward"]
+        for head, term in per_head.items():
+            if k > 0:
+                term = trainer_mod._scale_gradient(term, b["gradient_scales"][:, k])
+            sums[head] = sums[head] + term
+        with torch.no_grad():
+            predicted = models.support_to_scalar(value[k], support).squeeze(-1)
+            priorities[:, k] = torch.abs(predicted - b["values"][:, k]) ** alpha
+    loss = sums["value"] * vw + sums["reward"] + sums["policy"]
+    if b["weights"] is not None:
+        loss = loss * b["weights"]
+    return loss, sums, priorities
+
+
+@pytest.mark.parametrize("B,K1,support,A,per", [(128, 11, 10, 2, True), (32, 6, 10, 9, True), (7, 4, 300, 4, False),
+                                               (64, 3, 10, 7, True)])
+def test_unroll_loss_kernel_vs_torch(mods, B, K1, support, A, per):
+    trainer_mod, models = mods
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + K1)
+    F = 2 * support + 1
+    dev = "cuda"
+
+    def rand(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g, device=dev) * scale
+
+    value = [rand(B, F, scale=2.0).requires_grad_() for _ in range(K1)]
+    reward = [rand(B, F, scale=2.0).requires_grad_() for _ in range(K1)]
+    policy = [rand(B, A).requires_grad_() for _ in range(K1)]
+    with torch.no_grad():
+        reward[0].fill_(float("-inf"))           # initial_inference's reward: log(one_hot(centre))
+        reward[0][:, support] = 0.0
+    b = {"values": rand(B, K1, scale=40.0), "rewards": rand(B, K1, scale=3.0),
+         "policies": torch.softmax(rand(B, K1, A), dim=2),
+         "gradient_scales": torch.randint(1, K1 + 1, (B, K1), generator=g, device=dev).float(),
+         "weights": (torch.rand(B, generator=g, device=dev) + 0.1) if per else None}
+    b["values"][0, 0] = 0.0                      # sign(0) branch
+    big = float(support + 5) ** 2 * 4            # targets beyond the support: clamped, the upper entry overflows
+    b["values"][1, 1] = big
+    b["rewards"][2, 1] = -big
+    b["policies"][3, 0] = 0.0                    # absorbing positions have all-zero policy targets... and uniform ones
+    vw, alpha = 0.25, 0.5
+
+    loss_ref, sums_ref, pri_ref = torch_reference(trainer_mod, models, value, reward, policy, b, support, vw, alpha)
+    loss_ref.mean().backward()
+    grads_ref = [torch.stack([t.grad if t.grad is not None else torch.zeros_like(t) for t in head])
+                 for head in (value, reward, policy)]
+    for head in (value, reward, policy):
+        for t in head:
+            t.grad = None
+
+    sv, sr, sp = (torch.stack(head) for head in (value, reward, policy))
+    sample_loss, head_sums, priorities = trainer_mod._UnrollLoss.apply(sv, sr, sp, b, support, vw, alpha)
+    sample_loss.mean().backward()
+    grads = [torch.stack([t.grad if t.grad is not None else torch.zeros_like(t) for t in head])
+             for head in (value, reward, policy)]
+
+    def close(a, ref, tol):
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((a - ref).abs().max()) <= tol * scale, float((a - ref).abs().max()) / scale
+
+    close(sample_loss, loss_ref.detach(), 2e-6)
+    for i, head in enumerate(("value", "reward", "policy")):
+        close(head_sums[i], sums_ref[head].detach(), 2e-6)
+    close(priorities, pri_ref, 1e-5)
+    for got, ref in zip(grads, grads_ref):
+        close(got, ref, 2e-6)
+    assert float(grads[1][0].abs().max()) == 0.0     # nothing flows into the root position's reward logits

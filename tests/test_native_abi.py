@@ -19,10 +19,10 @@ def native(pkg):
 
 def declared_symbols():
     names = set()
-    for header in ("mzmcts.h", "mzenv.h", "mzreplay.h", "mzhist.h"):
+    for header in ("mzmcts.h", "mzenv.h", "mzreplay.h", "mzhist.h", "mztrain.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names |= set(re.findall(r"\b(mz(?:mcts|env|replay|hist)_[a-z0-9_]+)\s*\(", text))
+        names |= set(re.findall(r"\b(mz(?:mcts|env|replay|hist|train)_[a-z0-9_]+)\s*\(", text))
     return sorted(names)
 
 
