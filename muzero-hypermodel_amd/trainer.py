@@ -72,8 +72,13 @@ class _UnrollLoss(torch.autograd.Function):
 class Trainer:
     native_loss = True      # on the GPU: the loss of a step as one HIP launch (False: the torch expression, for timing)
 
-    def __init__(self, initial_checkpoint, config, device=None):
+    def __init__(self, initial_checkpoint, config, device=None, graph=False):
+        """graph=True (GPU, Adam): the whole step -- unroll, loss launch, backward, optimizer -- is captured into a
+        hipGraph at the first update_weights and replayed afterwards (the step is launch-bound: ~1 500 launches of
+        microsecond kernels for the CartPole network); batches are copied into the capture's static buffers."""
         self.config = config
+        self._graph_mode = bool(graph)
+        self._graph = None
         numpy.random.seed(self.config.seed)
         torch.manual_seed(self.config.seed)
         self.model = models.MuZeroNetwork(self.config)
@@ -87,11 +92,18 @@ class Trainer:
             self.optimizer = torch.optim.SGD(self.model.parameters(), lr=self.config.lr_init,
                                              momentum=self.config.momentum, weight_decay=self.config.weight_decay)
         elif self.config.optimizer == "Adam":
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.config.lr_init,
-                                              weight_decay=self.config.weight_decay)
+            if self._graph_mode:        # step counter and learning rate live on the device, so a replay can move them
+                self._lr = torch.tensor(float(self.config.lr_init), device=torch.device(device))
+                self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self._lr, capturable=True,
+                                                  weight_decay=self.config.weight_decay)
+            else:
+                self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.config.lr_init,
+                                                  weight_decay=self.config.weight_decay)
         else:
             raise NotImplementedError(
                 f"{self.config.optimizer} is not implemented. You can change the optimizer manually in trainer.py.")
+        if self._graph_mode and (self.config.optimizer != "Adam" or torch.device(device).type != "cuda"):
+            raise NotImplementedError("Trainer(graph=True) captures an Adam step on the GPU")
         if initial_checkpoint.get("optimizer_state") is not None:
             self.optimizer.load_state_dict(copy.deepcopy(initial_checkpoint["optimizer_state"]))
 
@@ -158,6 +170,8 @@ class Trainer:
     def update_weights(self, batch):
         cfg = self.config
         b = self._batch_on_device(batch)
+        if self._graph_mode:
+            return self._step_graphed(b)
         steps = self._unroll(b["observations"], b["actions"])
         if b["values"].is_cuda and self.native_loss:
             return self._step_native(b, steps)
@@ -195,11 +209,9 @@ class Trainer:
         (_UnrollLoss): the logits of all unrolled positions are stacked step-major, the kernel returns the
         per-sample loss and keeps its gradient for backward."""
         cfg = self.config
-        value = torch.stack([s[0] for s in steps])
-        reward = torch.stack([s[1] for s in steps])
-        policy = torch.stack([s[2] for s in steps])
-        sample_loss, head_sums, priorities = _UnrollLoss.apply(value, reward, policy, b, cfg.support_size,
-                                                               cfg.value_loss_weight, cfg.PER_alpha)
+        sample_loss, head_sums, priorities = _UnrollLoss.apply(
+            torch.stack([s[0] for s in steps]), torch.stack([s[1] for s in steps]), torch.stack([s[2] for s in steps]), b,
+            cfg.support_size, cfg.value_loss_weight, cfg.PER_alpha)
         loss = sample_loss.mean()
         self.optimizer.zero_grad()
         loss.backward()
@@ -208,8 +220,59 @@ class Trainer:
         report = torch.cat([loss.detach().reshape(1), head_sums.mean(dim=1)]).tolist()     # one device-to-host copy
         return (priorities.cpu().numpy(), report[0], report[1], report[2], report[3])
 
+    def _loss_native(self, b):
+        steps = self._unroll(b["observations"], b["actions"])
+        cfg = self.config
+        return _UnrollLoss.apply(torch.stack([s[0] for s in steps]), torch.stack([s[1] for s in steps]),
+                                 torch.stack([s[2] for s in steps]), b, cfg.support_size, cfg.value_loss_weight,
+                                 cfg.PER_alpha)
+
+    def _step_graphed(self, b):
+        """update_weights as one hipGraph replay: the first call warms the step up eagerly on a side stream (what
+        stream capture requires), captures it on static copies of the batch, and every call copies its batch in,
+        replays, and reads loss / head sums / priorities out of the capture's output tensors."""
+        if self._graph is None:
+            self._static = {k: (v.clone() if v is not None else None) for k, v in b.items()}
+            side = torch.cuda.Stream(device=b["values"].device)
+            side.wait_stream(torch.cuda.current_stream(b["values"].device))
+            state = (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.optimizer.state_dict()))
+            with torch.cuda.stream(side):
+                for _ in range(3):                       # warm-up steps, undone below
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self._loss_native(self._static)[0].mean().backward()
+                    self.optimizer.step()
+            torch.cuda.current_stream(b["values"].device).wait_stream(side)
+            self.model.load_state_dict(state[0])
+            # the optimizer's moments and step counters must exist BEFORE the capture (created inside it they would be
+            # re-initialised by every replay): keep the tensors the warm-up made, put the saved values back in place
+            live = self.optimizer.state_dict()["state"]
+            for index, entry in live.items():
+                saved = state[1]["state"].get(index)
+                for name, value in entry.items():
+                    if torch.is_tensor(value):
+                        value.copy_(saved[name]) if saved is not None else value.zero_()
+            self.optimizer.zero_grad(set_to_none=True)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                sample_loss, head_sums, priorities = self._loss_native(self._static)
+                loss = sample_loss.mean()
+                loss.backward()
+                self.optimizer.step()
+                self._graph_out = (torch.cat([loss.detach().reshape(1), head_sums.mean(dim=1)]), priorities)
+            # (the capture itself does not execute the step)
+        for key, value in b.items():
+            if value is not None:
+                self._static[key].copy_(value)
+        self._graph.replay()
+        self.training_step += 1
+        report = self._graph_out[0].tolist()
+        return (self._graph_out[1].cpu().numpy(), report[0], report[1], report[2], report[3])
+
     def update_lr(self):
         lr = self.config.lr_init * self.config.lr_decay_rate ** (self.training_step / self.config.lr_decay_steps)
+        if self._graph_mode:
+            self._lr.fill_(lr)
+            return
         for param_group in self.optimizer.param_groups:
             param_group["lr"] = lr
 

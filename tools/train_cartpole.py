@@ -40,7 +40,8 @@ def main():
     actor = sp.DeviceSelfPlay({"weights": weights}, "cartpole", config, args.seed, args.envs)
     actor.engine.set_fused_options("auto", publish_tree=False)
     replay = rb_mod.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
-    trainer = tr_mod.Trainer({"weights": weights, "training_step": 0, "optimizer_state": None}, config, device="cuda")
+    trainer = tr_mod.Trainer({"weights": weights, "training_step": 0, "optimizer_state": None}, config, device="cuda",
+                                graph="--eager-trainer" not in sys.argv)   # the step as one hipGraph replay
     flat = actor.engine._fc_flat                     # the buffer the actor's network (and the fused kernel) alias
     finished = []
 

@@ -21,8 +21,8 @@ for game in ("cartpole", "tictactoe"):
              torch.softmax(torch.randn(B, K1, A, generator=g, device="cuda"), dim=2),
              torch.rand(B, generator=g, device="cuda") + 0.5,
              torch.randint(1, K1 + 1, (B, K1), generator=g, device="cuda").float())
-    for native in (True, False):
-        trainer = pkg("trainer").Trainer(ckpt, config, device="cuda")
+    for native, graph in ((True, True), (True, False), (False, False)):
+        trainer = pkg("trainer").Trainer(ckpt, config, device="cuda", graph=graph)
         trainer.native_loss = native
         for _ in range(10):
             trainer.update_weights(batch)
@@ -32,5 +32,5 @@ for game in ("cartpole", "tictactoe"):
         for _ in range(n):
             trainer.update_weights(batch)
         torch.cuda.synchronize()
-        print(json.dumps({"config": game, "batch": B, "unrolled_positions": K1, "loss": "one HIP launch" if native else "torch expression",
+        print(json.dumps({"config": game, "batch": B, "unrolled_positions": K1, "loss": "one HIP launch" if native else "torch expression", "hipgraph": graph,
                           "ms_per_training_step": round((time.perf_counter() - t0) / n * 1e3, 3)}), flush=True)
