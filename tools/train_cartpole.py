@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--moves", type=int, default=8, help="self-play moves per env and iteration (one move batch)")
     ap.add_argument("--train-steps", type=int, default=100, help="training steps per iteration")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--eager-trainer", action="store_true", help="launch the training step op by op instead of as one hipGraph replay")
     args = ap.parse_args()
     sp = importlib.import_module("muzero-hypermodel_amd.self_play")
     rb_mod = importlib.import_module("muzero-hypermodel_amd.replay_buffer")
@@ -41,7 +42,7 @@ def main():
     actor.engine.set_fused_options("auto", publish_tree=False)
     replay = rb_mod.ReplayBuffer({"num_played_games": 0, "num_played_steps": 0}, {}, config)
     trainer = tr_mod.Trainer({"weights": weights, "training_step": 0, "optimizer_state": None}, config, device="cuda",
-                                graph="--eager-trainer" not in sys.argv)   # the step as one hipGraph replay
+                                graph=not args.eager_trainer)   # the step as one hipGraph replay
     flat = actor.engine._fc_flat                     # the buffer the actor's network (and the fused kernel) alias
     finished = []
 
