@@ -59,11 +59,16 @@ F16_MATRIX_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide; the 2
 # to another CPU, kept only as a labelled side figure; `cpu_baseline.value` is the port itself.
 RHO_PORT_OVER_REFERENCE = {"cartpole": 208.0}
 
+# Envs (trees) per GPU.  BASELINE.json fixes it for config #2 only (4096 CartPole envs); for the lock-step configs it is
+# the actor's choice, and one MI355X (288 GB) is best used with many more trees than 4096: the per-simulation launches
+# (tower, heads, select, gather, expand_backup) are filled better and their fixed costs amortised -- TicTacToe 37 M
+# simulations/s at 4096 envs, 63 M at 16384, 75 M at 65536; Connect4 4.0 / 4.2 / 4.5 M at 1024 / 2048 / 4096; the
+# 84x84 config 9.9 / 17.0 / 20.6 M at 1024 / 4096 / 16384.
 WORKLOADS = {
     "cartpole": dict(envs=4096, baseline_config=2),
-    "tictactoe": dict(envs=4096, baseline_config=3),
-    "connect4": dict(envs=1024, baseline_config=4),
-    "atari84": dict(envs=1024, baseline_config=5),
+    "tictactoe": dict(envs=65536, baseline_config=3),
+    "connect4": dict(envs=4096, baseline_config=4),
+    "atari84": dict(envs=16384, baseline_config=5),
 }
 
 
@@ -82,9 +87,9 @@ def parse_args(argv=None):
                     help="the K timed steps are repeated until the timed region lasts at least this long")
     ap.add_argument("--bcast-every", type=int, default=50, help="weight broadcast period in steps (N>1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--device-noise", action="store_true",
-                    help="draw the exploration noise on the GPU instead of on the host mirrors of the RNG streams "
-                         "(lock-step workloads; the same rows to the last bit)")
+    ap.add_argument("--host-noise", action="store_true",
+                    help="lock-step workloads: draw the exploration noise on the host mirrors of the RNG streams instead "
+                         "of on the GPU (the same rows to the last bit; 5 % slower at 65536 TicTacToe envs)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event pass (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="budget of each cpu_baseline leg, 1 core and all cores (0 = skip)")
@@ -247,7 +252,7 @@ class Workload:
         actor_mod = pkg("actor")
         self.actor = actor_mod.SearchActor(self.config, weights, self.E, rank=rank, device=device,
                                            use_graph=not args.no_graph, group_width=group, fused_fc=self.fused,
-                                           device_noise=args.device_noise)
+                                           device_noise=not self.fused and not args.host_noise)
         self.engine, self.model = self.actor.engine, self.actor.model
         self.engine.fused_hidden_in_lds = not args.hidden_in_hbm
         rs = np.random.RandomState(123 + rank)
@@ -497,6 +502,8 @@ def main(argv=None):
                    "fused_kernel": engine.fused_variant() if fused else None,
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),
                    "parallelism": f"actors{world}",
+                   "exploration_noise": "drawn on the GPU (root_noise_kernel)" if engine._device_noise else
+                                        "drawn on the host mirrors of the RNG streams",
                    "weight_broadcast_every_steps": args.bcast_every if world > 1 else None},
         "timed_steps": timed_steps, "timed_seconds": elapsed, "repeats_of_steps": repeats,
         "self_play_moves_per_sec": moves_played / elapsed,

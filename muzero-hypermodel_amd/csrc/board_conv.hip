@@ -945,15 +945,23 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
+    // Samples per workgroup.  A 16-channel tower has ONE column tile, so its 8 wavefronts split the SB x H x W output
+    // rows into 16-row tiles, every wavefront running the same number of tiles per k-step: with few boards SB is small
+    // (more workgroups than CUs matters most), with many it is the SB whose rows fill a whole number of rounds --
+    // 28 x 9 = 252 rows = 15.75 tiles in 2 rounds of 8 (16 x 9 = 144 rows = 9 tiles also takes 2 rounds: 44 % idle).
+    const bool many = b >= 16384;
     if (height == 6 && width == 7) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream);
+        if (many && (cin0 * 42) % 2 == 0) return mz::launch_board_tower<1, 6, 7, 6>(x, b, cin0, args, stream);
         return mz::launch_board_tower<1, 6, 7, 4>(x, b, cin0, args, stream);
     }
     if (height == 6 && width == 6) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream);
+        if (many) return mz::launch_board_tower<1, 6, 6, 7>(x, b, cin0, args, stream);
         return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream);
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
+    if (many) return mz::launch_board_tower<1, 3, 3, 28>(x, b, cin0, args, stream);
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream);
 }
 

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/mzmcts.h"
 
@@ -255,6 +256,277 @@ __global__ __launch_bounds__(64 * kHeadWaves) void conv_head_kernel(HeadSet set,
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// The same heads on the matrix cores, 16 samples per wavefront and step (exact fp32, v_mfma_f32_16x16x4_f32).  The
+// wave-per-sample kernel above is bound by instruction issue -- a multiply-add costs two LDS reads and an index update
+// -- which at 65536 TicTacToe boards made the heads a third of a simulation step.  Here the three layers are three small
+// GEMMs per 16-sample tile:
+//     1x1 convolution  rows = (sample, position) pairs (16 P rows = P tiles), K = channels, N = reduced channels (<= 16);
+//                      the A operand comes straight from the NCHW board (16 lanes read 16 consecutive positions of a
+//                      channel), the weights wait in registers; y goes to LDS as [sample][r P + p], the Linear's input
+//     Linear + ELU     rows = samples, K = R P, N = hidden units (<= 64), weights in LDS; h to LDS as [sample][unit]
+//     Linear           rows = samples, K = hidden, N = outputs (<= 32); logits to global
+// Every output is a k-ordered chain of fused multiply-adds in the matrix pipe (the order differs from the kernel above
+// and from hipBLASLt: equal to fp32 rounding, tests/test_gpu_net.py).
+// -------------------------------------------------------------------------------------------------------------------
+typedef float head_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTileSamples = 16;
+constexpr int kMaxConvSteps = 16;   // channels / 4 <= 16: the 1x1 convolution's weights stay in registers (4 or 16 k-steps)
+
+struct MfmaHeadShape {
+    int C, P, R, Hd, O;
+    __host__ __device__ int RP() const { return R * P; }
+    __host__ __device__ int ys_stride() const { return RP() + 1; }      // (+1: the 16 sample rows fall into different banks)
+    __host__ __device__ int hs_stride() const { return Hd + 1; }
+    __host__ __device__ int w1_stride() const { return RP() + 1; }
+    __host__ __device__ int w2_stride() const { return Hd + 1; }
+    __host__ __device__ int nt1() const { return (Hd + 15) / 16; }
+    __host__ __device__ int nt2() const { return (O + 15) / 16; }
+    // LDS (floats): W1 [16 nt1][w1_stride] | b1 [16 nt1] | W2 [16 nt2][w2_stride] | b2 [16 nt2] | per wave { ys, hs }
+    __host__ __device__ int off_b1() const { return 16 * nt1() * w1_stride(); }
+    __host__ __device__ int off_w2() const { return off_b1() + 16 * nt1(); }
+    __host__ __device__ int off_b2() const { return off_w2() + 16 * nt2() * w2_stride(); }
+    __host__ __device__ int off_waves() const { return off_b2() + 16 * nt2(); }
+    __host__ __device__ int wave_floats() const { return kTileSamples * (ys_stride() + hs_stride()); }
+    __host__ __device__ int total() const { return off_waves() + kHeadWaves * wave_floats(); }
+};
+
+struct MfmaHeadSet {
+    const float* x[kMaxHeads];
+    mzmcts_head_desc desc[kMaxHeads];
+    MfmaHeadShape shape[kMaxHeads];
+    float* out[kMaxHeads];
+};
+
+// KS = k-steps of the 1x1 convolution (channels / 4, rounded up to 4 or 16), G = row tiles whose board values a lane
+// keeps in registers at once: the values of the NEXT chunk of G tiles -- of this 16-sample tile or of the wave's next
+// one -- are requested before the current chunk goes through the matrix pipe, so the L2 round trip of a chunk hides
+// under the chunk before it.
+template <int NT1, int NT2, int KS, int G>
+__device__ __forceinline__ void mfma_head_tiles(const MfmaHeadShape& s, const mzmcts_head_desc& d, const float* __restrict__ x,
+                                                float* __restrict__ out, float* lds, int batch, int lane, int wave) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int RP = s.RP(), CP = s.C * s.P;
+    const float* w1 = lds;
+    const float* b1 = lds + s.off_b1();
+    const float* w2 = lds + s.off_w2();
+    const float* b2 = lds + s.off_b2();
+    float* ys = lds + s.off_waves() + wave * s.wave_floats();
+    float* hs = ys + kTileSamples * s.ys_stride();
+    // 1x1 convolution weights of this lane: B[k = 4 ks + kk][n = i] = conv_w[i][4 ks + kk]
+    float wc[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int c = 4 * ks + kk;
+        wc[ks] = (i < s.R && c < s.C) ? d.conv_w[i * s.C + c] : 0.f;
+    }
+    const float conv_bias = i < s.R ? d.conv_b[i] : 0.f;
+
+    const int tiles = (batch + kTileSamples - 1) / kTileSamples;
+    const int stride = gridDim.x * kHeadWaves;
+    // m / P for the row indices m <= 16 P + 15 of a tile, without an integer division per use (exact while m P < 2^20)
+    const uint32_t p_magic = ((1u << 20) + static_cast<uint32_t>(s.P) - 1u) / static_cast<uint32_t>(s.P);
+    auto div_p = [&](int m) { return static_cast<int>((static_cast<uint32_t>(m) * p_magic) >> 20); };
+    // rows of row tile t: m = 16 t + (0..15), m = sample * P + position
+    auto load_chunk = [&](int tile, int c0, float (&dst)[G][KS]) {
+        const int b0 = tile * kTileSamples;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int t = c0 + g;
+            const int m = 16 * t + i;                       // this lane's A row
+            const int sa = div_p(m), pa = m - sa * s.P;
+            const bool live = tile < tiles && t < s.P && b0 + sa < batch;
+            const float* row = x + static_cast<size_t>(b0 + sa) * CP + pa;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = 4 * ks + kk;
+                dst[g][ks] = (live && c < s.C) ? row[c * s.P] : 0.f;
+            }
+        }
+    };
+    int tile = blockIdx.x * kHeadWaves + wave;
+    int c0 = 0;
+    float cur[G][KS], nxt[G][KS];
+    load_chunk(tile, 0, cur);
+    while (tile < tiles) {
+        const int b0 = tile * kTileSamples;
+        const bool last_chunk = c0 + G >= s.P;
+        const int ntile = last_chunk ? tile + stride : tile;
+        const int nc0 = last_chunk ? 0 : c0 + G;
+        load_chunk(ntile, nc0, nxt);
+        // ---- 1x1 convolution of this chunk's row tiles (k-step outermost: consecutive MFMAs belong to different tiles,
+        //      a dependent accumulate would wait out the matrix pipe's latency) ----------------------------------------
+        {
+            head_f32x4 acc[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = head_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[g][ks], wc[ks], acc[g], 0, 0, 0);
+            if (i < s.R) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int t = c0 + g;
+                    if (t < s.P) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {       // D[row = 4 kk + r][col = i]
+                            const int md = 16 * t + 4 * kk + r;
+                            const int sd = div_p(md), pd = md - sd * s.P;
+                            ys[sd * s.ys_stride() + i * s.P + pd] = acc[g][r] + conv_bias;
+                        }
+                    }
+                }
+            }
+        }
+        if (last_chunk) {
+            wave_sync();
+            // ---- Linear + ELU: h[sample][unit] = elu(sum_k y[sample][k] W1[unit][k] + b1[unit]) ----------------------
+            {
+                // (kParts accumulators per column tile take the k-steps in turn and are added at the end, so that
+                // consecutive MFMAs are independent also when there is a single column tile)
+                constexpr int kParts = NT1 >= 4 ? 1 : 4;
+                head_f32x4 part[NT1][kParts];
+#pragma unroll
+                for (int n = 0; n < NT1; ++n)
+#pragma unroll
+                    for (int q = 0; q < kParts; ++q) part[n][q] = head_f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* yrow = ys + i * s.ys_stride();
+                const int steps = (RP + 3) / 4;
+                for (int ks0 = 0; ks0 < steps; ks0 += kParts) {
+#pragma unroll
+                    for (int q = 0; q < kParts; ++q) {
+                        const int k = 4 * (ks0 + q) + kk;
+                        const bool in = ks0 + q < steps && k < RP;
+                        const float a = in ? yrow[k] : 0.f;
+#pragma unroll
+                        for (int n = 0; n < NT1; ++n) {
+                            const float b = in ? w1[(16 * n + i) * s.w1_stride() + k] : 0.f;
+                            part[n][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, part[n][q], 0, 0, 0);
+                        }
+                    }
+                }
+                head_f32x4 acc[NT1];
+#pragma unroll
+                for (int n = 0; n < NT1; ++n) {
+                    acc[n] = part[n][0];
+#pragma unroll
+                    for (int q = 1; q < kParts; ++q) acc[n] = acc[n] + part[n][q];
+                }
+#pragma unroll
+                for (int n = 0; n < NT1; ++n) {
+                    const int unit = 16 * n + i;
+                    if (unit < s.Hd) {
+                        const float bias = b1[unit];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[n][r] + bias;
+                            hs[(4 * kk + r) * s.hs_stride() + unit] = v > 0.f ? v : expf(v) - 1.f;
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            // ---- Linear: logits[sample][o] --------------------------------------------------------------------------------
+            {
+                head_f32x4 acc[NT2];
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) acc[n] = head_f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* hrow = hs + i * s.hs_stride();
+                const int steps = (s.Hd + 3) / 4;
+                for (int ks = 0; ks < steps; ++ks) {
+                    const int k = 4 * ks + kk;
+                    const float a = k < s.Hd ? hrow[k] : 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT2; ++n) {
+                        const float b = k < s.Hd ? w2[(16 * n + i) * s.w2_stride() + k] : 0.f;
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT2; ++n) {
+                    const int o = 16 * n + i;
+                    if (o < s.O) {
+                        const float bias = b2[o];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int sample = b0 + 4 * kk + r;
+                            if (sample < batch) out[static_cast<size_t>(sample) * s.O + o] = acc[n][r] + bias;
+                        }
+                    }
+                }
+            }
+            wave_sync();   // (the next tile rewrites ys / hs)
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) cur[g][ks] = nxt[g][ks];
+        tile = ntile;
+        c0 = nc0;
+    }
+}
+
+template <int KS, int G>
+__device__ __forceinline__ void mfma_head_dispatch(const MfmaHeadShape& s, const mzmcts_head_desc& d, const float* __restrict__ x,
+                                                   float* __restrict__ out, float* lds, int batch, int lane, int wave) {
+    const int nt1 = s.nt1(), nt2 = s.nt2();
+    if (nt1 == 1 && nt2 == 1) mfma_head_tiles<1, 1, KS, G>(s, d, x, out, lds, batch, lane, wave);
+    else if (nt1 == 1 && nt2 == 2) mfma_head_tiles<1, 2, KS, G>(s, d, x, out, lds, batch, lane, wave);
+    else if (nt2 == 1) mfma_head_tiles<4, 1, KS, G>(s, d, x, out, lds, batch, lane, wave);
+    else mfma_head_tiles<4, 2, KS, G>(s, d, x, out, lds, batch, lane, wave);
+}
+
+__global__ __launch_bounds__(64 * kHeadWaves) void conv_head_mfma_kernel(MfmaHeadSet set, int batch) {
+    const float* __restrict__ x = set.x[blockIdx.y];
+    const mzmcts_head_desc d = set.desc[blockIdx.y];
+    const MfmaHeadShape s = set.shape[blockIdx.y];
+    float* __restrict__ out = set.out[blockIdx.y];
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kThreads = 64 * kHeadWaves;
+    // Linear weights, rows padded to whole 16-row tiles with zeros (so the B operand needs no row guard)
+    const int RP = s.RP();
+    // zeros first (padding rows / columns), then the weights with eight independent loads per thread in flight: the
+    // staging is latency, not bandwidth
+    for (int idx = tid; idx < s.off_waves(); idx += kThreads) lds[idx] = 0.f;
+    __syncthreads();
+    auto stage_rows = [&](float* dst, const float* __restrict__ src, int rows, int cols, int dst_stride) {
+        constexpr int kInFlight = 8;
+        const int n = rows * cols;
+        const uint32_t magic = ((1u << 20) + static_cast<uint32_t>(cols) - 1u) / static_cast<uint32_t>(cols);
+        const bool fast = static_cast<int64_t>(n) * cols < (1 << 20);       // (exactness bound of the magic division)
+        for (int base = tid; base < n; base += kThreads * kInFlight) {
+            float v[kInFlight];
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const int idx = base + u * kThreads;
+                v[u] = idx < n ? src[idx] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const int idx = base + u * kThreads;
+                if (idx < n) {
+                    const int row = fast ? static_cast<int>((static_cast<uint32_t>(idx) * magic) >> 20) : idx / cols;
+                    dst[row * dst_stride + (idx - row * cols)] = v[u];
+                }
+            }
+        }
+    };
+    stage_rows(lds, d.fc1_w, s.Hd, RP, s.w1_stride());
+    stage_rows(lds + s.off_b1(), d.fc1_b, 1, s.Hd, s.Hd);
+    stage_rows(lds + s.off_w2(), d.fc2_w, s.O, s.Hd, s.w2_stride());
+    stage_rows(lds + s.off_b2(), d.fc2_b, 1, s.O, s.O);
+    __syncthreads();
+    if (s.C <= 16) mfma_head_dispatch<4, 6>(s, d, x, out, lds, batch, lane, wave);
+    else mfma_head_dispatch<16, 2>(s, d, x, out, lds, batch, lane, wave);
+}
+
+// shapes the matrix-core heads take: reduced channels <= 16 (one column tile), channels <= 64, hidden <= 64, outputs <= 32
+static bool mfma_head_ok(const mzmcts_head_desc& d) {
+    return d.reduced <= 16 && d.channels <= 4 * kMaxConvSteps && d.hidden <= 64 && d.outputs <= 32;
+}
+
 // The dynamics network's input (reference models.py:553-568): the hidden state's planes followed by one plane
 // holding action / action_space_size -- through torch a cast, a division, an expand and a concatenation.
 __global__ __launch_bounds__(256) void state_action_planes_kernel(const float* __restrict__ state,
@@ -308,6 +580,39 @@ extern "C" int mzmcts_conv_heads_multi(const float* const* xs, const mzmcts_head
         return MZMCTS_ERR_INVALID;
     for (int h = 0; h < n_heads; ++h)
         if (!xs[h] || (reinterpret_cast<uintptr_t>(xs[h]) & 15u)) return MZMCTS_ERR_INVALID;
+    static const bool use_mfma = std::getenv("MZ_HEADS_WAVE_PER_SAMPLE") == nullptr;
+    bool mfma = use_mfma && batch >= mz::kTileSamples;
+    for (int h = 0; h < n_heads && mfma; ++h) mfma = mz::mfma_head_ok(heads[h]);
+    if (mfma) {
+        mz::MfmaHeadSet mset{};
+        size_t mlds = 0;
+        for (int h = 0; h < n_heads; ++h) {
+            const mzmcts_head_desc* d = heads + h;
+            if (!outs[h] || !d->conv_w || !d->conv_b || !d->fc1_w || !d->fc1_b || !d->fc2_w || !d->fc2_b || d->channels <= 0 ||
+                d->plane <= 0 || d->reduced <= 0 || d->hidden <= 0 || d->outputs <= 0 || d->channels != heads[0].channels ||
+                d->plane != heads[0].plane)
+                return MZMCTS_ERR_INVALID;
+            mset.x[h] = xs[h];
+            mset.desc[h] = *d;
+            mset.shape[h] = mz::MfmaHeadShape{d->channels, d->plane, d->reduced, d->hidden, d->outputs};
+            mset.out[h] = outs[h];
+            mlds = std::max(mlds, sizeof(float) * static_cast<size_t>(mset.shape[h].total()));
+        }
+        if (mlds <= 160 * 1024) {
+            if (batch == 0) return MZMCTS_OK;
+            if (mlds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(mz::conv_head_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mlds)) != hipSuccess)
+                return MZMCTS_ERR_HIP;
+            const int64_t tiles = (batch + mz::kTileSamples - 1) / mz::kTileSamples;
+            const int64_t rounds = (tiles + mz::kHeadWaves - 1) / mz::kHeadWaves;
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / mlds)));
+            const dim3 grid(static_cast<unsigned>(std::min<int64_t>(rounds, 256 * per_cu)), static_cast<unsigned>(n_heads));
+            mz::conv_head_mfma_kernel<<<grid, dim3(64 * mz::kHeadWaves), mlds, static_cast<hipStream_t>(stream_)>>>(
+                mset, static_cast<int>(batch));
+            return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+        }
+    }
     mz::HeadSet set{};
     size_t lds = 0;
     for (int h = 0; h < n_heads; ++h) {
