@@ -946,9 +946,12 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
     // Samples per workgroup.  A 16-channel tower has ONE column tile, so its 8 wavefronts split the SB x H x W output
-    // rows into 16-row tiles, every wavefront running the same number of tiles per k-step: with few boards SB is small
-    // (more workgroups than CUs matters most), with many it is the SB whose rows fill a whole number of rounds --
-    // 28 x 9 = 252 rows = 15.75 tiles in 2 rounds of 8 (16 x 9 = 144 rows = 9 tiles also takes 2 rounds: 44 % idle).
+    // rows into 16-row tiles and every wavefront runs ceil(tiles / 8) of them per k-step: 16 x 9 = 144 rows = 9 tiles
+    // cost two rounds for little more than one round's work.  With few boards that choice stands (more workgroups than
+    // CUs matters most); with many, SB is the count whose rows fit ONE round and whose LDS lets two or more workgroups
+    // share a CU, so that one's fill / epilogue / export phases run under another's MFMAs: 12 x 9 = 108 rows = 7 tiles
+    // (measured at 65536 TicTacToe boards: SB 16 / 28 / 12 = 318 / 313 / 300 us per launch; 6x6, 16384 boards:
+    // SB 4 / 7 / 3 = 513 / 513 / 428 us).
     const bool many = b >= 16384;
     if (height == 6 && width == 7) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream);
@@ -957,11 +960,11 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     }
     if (height == 6 && width == 6) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream);
-        if (many) return mz::launch_board_tower<1, 6, 6, 7>(x, b, cin0, args, stream);
+        if (many) return mz::launch_board_tower<1, 6, 6, 3>(x, b, cin0, args, stream);
         return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream);
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
-    if (many) return mz::launch_board_tower<1, 3, 3, 28>(x, b, cin0, args, stream);
+    if (many) return mz::launch_board_tower<1, 3, 3, 12>(x, b, cin0, args, stream);
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream);
 }
 
