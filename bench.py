@@ -59,16 +59,22 @@ F16_MATRIX_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide; the 2
 # to another CPU, kept only as a labelled side figure; `cpu_baseline.value` is the port itself.
 RHO_PORT_OVER_REFERENCE = {"cartpole": 208.0}
 
-# Envs (trees) per GPU.  BASELINE.json fixes it for config #2 only (4096 CartPole envs); for the lock-step configs it is
-# the actor's choice, and one MI355X (288 GB) is best used with many more trees than 4096: the per-simulation launches
-# (tower, heads, select, gather, expand_backup) are filled better and their fixed costs amortised -- TicTacToe 37 M
-# simulations/s at 4096 envs, 63 M at 16384, 75 M at 65536; Connect4 4.0 / 4.2 / 4.5 M at 1024 / 2048 / 4096; the
-# 84x84 config 9.9 / 17.0 / 20.6 M at 1024 / 4096 / 16384.
+# Envs (trees) per GPU and engines they are split into.  BASELINE.json fixes the env count for config #2 only (4096
+# CartPole envs); for the lock-step configs it is the actor's choice, and one MI355X (288 GB) is best used with many more
+# trees than 4096: the per-simulation launches (tower, heads, select, gather, expand_backup) are filled better and their
+# fixed costs amortised -- TicTacToe 37 M simulations/s at 4096 envs, 63 M at 16384, 75 M at 65536; Connect4 4.0 / 4.2 /
+# 4.5 M at 1024 / 2048 / 4096; the 84x84 config 9.9 / 17.0 / 20.6 M at 1024 / 4096 / 16384 (first measurements of round
+# 2, one engine).
+# groups: the envs of a GPU as that many engines on streams of their own (engine.PipelinedLockstep): one group's host work
+# -- readout, action sampling, the next move's checks and uploads -- runs under the other groups' kernels, and the kernels
+# of two streams fill each other's gaps: TicTacToe 65536 envs 98 -> 162 M simulations/s with two groups (four: 159 M;
+# 131072 envs: 170 M), Connect4 4096 envs 4.9 -> 5.4 M, 8192 envs 5.8 M (16384: 5.8 M), the 84x84 config 16384 envs
+# 25.1 -> 24.3 M but 32768 envs 26.7 -> 30.5 M (65536: 30.8 M).
 WORKLOADS = {
-    "cartpole": dict(envs=4096, baseline_config=2),
-    "tictactoe": dict(envs=65536, baseline_config=3),
-    "connect4": dict(envs=4096, baseline_config=4),
-    "atari84": dict(envs=16384, baseline_config=5),
+    "cartpole": dict(envs=4096, baseline_config=2, groups=2),
+    "tictactoe": dict(envs=65536, baseline_config=3, groups=2),
+    "connect4": dict(envs=8192, baseline_config=4, groups=2),
+    "atari84": dict(envs=32768, baseline_config=5, groups=2),
 }
 
 
@@ -100,15 +106,19 @@ def parse_args(argv=None):
                          "lockstep: select -> PyTorch-ROCm inference -> expand_backup per simulation")
     ap.add_argument("--group", type=int, default=0, help="lanes per tree (0 = default for the mode)")
     ap.add_argument("--hidden-in-hbm", action="store_true", help="fused mode: keep hidden states out of LDS")
-    ap.add_argument("--groups", type=int, default=2,
-                    help="fused mode with --moves-per-batch 0: env groups per GPU on separate HIP streams")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="env groups per GPU on separate HIP streams, one group's host work under the others' kernels: "
+                         "lock-step workloads, and fused mode with --moves-per-batch 0 (0 = the workload's default)")
     ap.add_argument("--moves-per-batch", type=int, default=50,
                     help="fused mode: moves queued back to back per host round trip (mzmcts_moves_*); "
                          "0 = one host round trip per move, pipelined over --groups env groups")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU: run launch, rendezvous (gloo), weight broadcast, timing reduction and the JSON relay "
                          "with the search replaced by a sleep -- a test of the N>1 plumbing, never a measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.groups <= 0:
+        args.groups = WORKLOADS[args.workload]["groups"]
+    return args
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -268,10 +278,14 @@ class Workload:
             self.flat_obs = [o.reshape(self.E, -1).contiguous() for o in self.obs_sets]
         elif self.fused and args.groups > 1:
             self._init_pipeline(actor_mod, group)
+        elif not self.fused and args.groups > 1:
+            self._init_lockstep_pipeline(actor_mod)
 
     # ---- weight refresh (the one exchange step of the path) ---------------------------------------------------------
     def refresh(self):
         self.actor.refresh_weights(src=0)
+        if self.pipe is not None and hasattr(self.pipe, "refresh"):
+            self.pipe.refresh()                              # the other groups' network replicas follow
         self.refreshes += 1
 
     # ---- one move for every env, one host round trip per move -------------------------------------------------------
@@ -301,6 +315,18 @@ class Workload:
                                                   group_width=group)
         per = self.E // n
         self.g_obs = [[o.reshape(self.E, -1)[self.pipe.slice(g)].contiguous() for g in range(n)] for o in self.obs_sets]
+        self.g_in = (self.legal[:per], self.num_legal[:per], self.to_play[:per], self.temperature[:per])
+        self.started = [False] * n
+
+    # ---- lock-step workloads, several env groups on separate streams (one group's host work under the others' kernels)
+    def _init_lockstep_pipeline(self, actor_mod):
+        n = self.args.groups
+        self.pipe = pkg("engine").PipelinedLockstep(self.config, self.E, self.model, groups=n, device=self.device,
+                                                    seeds=actor_mod.shard_seeds(self.config.seed, self.rank, self.E),
+                                                    use_graph=not self.args.no_graph,
+                                                    device_noise=not self.args.host_noise)
+        per = self.E // n
+        self.g_obs = [[o[self.pipe.slice(g)].contiguous() for g in range(n)] for o in self.obs_sets]
         self.g_in = (self.legal[:per], self.num_legal[:per], self.to_play[:per], self.temperature[:per])
         self.started = [False] * n
 
@@ -497,7 +523,7 @@ def main(argv=None):
         "config": {"workload": f"{wl.name}_{E}envs_x_{S}sims", "baseline_config": WORKLOADS[wl.name]["baseline_config"],
                    "envs_per_gpu": E, "simulations": S, "actions": A, "network": network,
                    "mode": "fused" if fused else "lockstep", "lanes_per_tree": engine.group_width(),
-                   "env_groups_per_gpu": args.groups if (fused and not batched and args.groups > 1) else 1,
+                   "env_groups_per_gpu": args.groups if (wl.pipe is not None) else 1,
                    "moves_per_host_round_trip": args.moves_per_batch if batched else 1,
                    "fused_kernel": engine.fused_variant() if fused else None,
                    "launch": "one kernel per move" if fused else ("eager" if args.no_graph else "hipgraph"),

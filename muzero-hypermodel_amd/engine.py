@@ -595,6 +595,20 @@ class BatchedMCTS:
             self._run_simulations(model)
             return self.readout()
 
+    @torch.no_grad()
+    def search_begin(self, model, observations, legal_actions, to_play, add_exploration_noise=True, num_legal=None):
+        """Asynchronous form of the lock-step search: root inference, root expansion, the S simulations and the readout
+        copies are queued on this engine's stream (`self.stream`, or the current one) and the call returns; `readout()`
+        later waits for them.  `observations` must be a resident fp32 CUDA tensor.  Several engines on streams of their
+        own overlap one engine's host work (contract checks, unpacking, action sampling) with the others' kernels."""
+        stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device), torch.cuda.stream(stream):
+            value, reward, policy, hidden = model.initial_inference(observations)
+            self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
+            self.expand_roots(value, reward.contiguous(), policy, hidden)
+            self._run_simulations(model)
+            self._check(self._lib.mzmcts_readout_begin(self._h, self._stream()))
+
     def readout(self):
         self._check(self._lib.mzmcts_readout(self._h, ctypes.byref(self._stats_struct), self._stream()))
         if self._device_noise:          # the rows the GPU drew for this search (a host draw fills self.noise up front)
@@ -674,6 +688,53 @@ def _device_view(address, numel, dtype, device):
                                     "version": 2, "strides": None}
     assert itemsize * numel > 0
     return torch.as_tensor(_Span(), device=device)
+
+
+class PipelinedLockstep:
+    """E envs as `groups` lock-step engines of E / groups envs, each with a replica of the network and a stream of its
+    own: while the host finishes one group's move (readout, action sampling, the next move's contract checks and
+    uploads) the GPU runs the other groups' simulations.  Env e of the whole set keeps its RNG stream (seeds are passed
+    through in order), so the groups together play exactly what one engine of E envs plays."""
+
+    def __init__(self, config, num_envs, model, groups=2, device=None, seeds=None, use_graph=True, group_width=0,
+                 device_noise=False):
+        import copy
+        assert num_envs % groups == 0, "num_envs must be a multiple of groups"
+        self.groups, self.per_group = groups, num_envs // groups
+        seeds = list(range(num_envs)) if seeds is None else list(seeds)
+        self.engines, self.models = [], []
+        for g in range(groups):
+            lo, hi = g * self.per_group, (g + 1) * self.per_group
+            eng = BatchedMCTS(config, self.per_group, device=device, seeds=seeds[lo:hi], use_graph=use_graph,
+                              group_width=group_width)
+            eng.stream = torch.cuda.Stream(device=eng.device)
+            if device_noise:
+                eng.use_device_noise()
+            self.engines.append(eng)
+            # a replica per group: the network modules keep output buffers that a second search in flight would overwrite
+            self.models.append(model if g == 0 else copy.deepcopy(model))
+
+    def slice(self, g):
+        return slice(g * self.per_group, (g + 1) * self.per_group)
+
+    def refresh(self):
+        """After a weight refresh of group 0's model: the other replicas follow."""
+        state = self.models[0].state_dict()
+        for m in self.models[1:]:
+            m.load_state_dict(state)
+
+    def begin(self, g, observations, legal, to_play, add_exploration_noise=True, num_legal=None):
+        eng = self.engines[g]
+        eng.stream.wait_stream(torch.cuda.current_stream(eng.device))
+        eng.search_begin(self.models[g], observations, legal, to_play, add_exploration_noise, num_legal)
+
+    def finish(self, g):
+        """Wait for group g's search; returns its stats dict (valid until its next begin)."""
+        return self.engines[g].readout()
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()
 
 
 class PipelinedSearch:

@@ -650,3 +650,49 @@ def test_batched_self_play_cartpole_fused(eng, models_mod, pkg):
         assert all(abs(sum(cv) - 1.0) < 1e-12 for cv in gh.child_visits)
         assert np.asarray(gh.observation_history[0]).shape == config.observation_shape
         assert set(gh.action_history[1:]) <= {0, 1} and all(r == 1.0 for r in gh.reward_history[1:])
+
+
+def test_pipelined_lockstep_groups_equal_one_engine(eng, models_mod):
+    """engine.PipelinedLockstep: the envs as two lock-step engines on streams of their own (one group's host work under
+    the other's kernels, network replica per group) play exactly what one engine of all envs plays -- noise, visit counts,
+    value sums, sampled actions -- over two consecutive moves (TicTacToe residual network, masked roots)."""
+    import importlib
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    E = 64
+    rs = np.random.RandomState(9)
+    obs = torch.from_numpy(rs.randint(-1, 2, (E, 3, 3, 3)).astype(np.float32)).cuda()
+    legal = np.zeros((E, 9), np.int32)
+    num_legal = rs.randint(1, 10, E).astype(np.int32)
+    for e in range(E):
+        legal[e, :num_legal[e]] = np.sort(rs.permutation(9)[:num_legal[e]])
+    to_play = rs.randint(0, 2, E).astype(np.int32)
+    seeds = list(range(500, 500 + E))
+
+    single = eng.BatchedMCTS(config, E, seeds=seeds)
+    want = []
+    for _ in range(2):
+        st = single.search(model, obs, legal, to_play, True, num_legal=num_legal)
+        actions, _ = single.sample_actions(1.0)
+        want.append(({k: v.copy() for k, v in st.items()}, single.noise.copy(), actions))
+    single.close()
+
+    pipe = eng.PipelinedLockstep(config, E, model, groups=2, seeds=seeds, use_graph=False)
+    got = []
+    for _ in range(2):
+        for g in range(2):
+            sl = pipe.slice(g)
+            pipe.begin(g, obs[sl].contiguous(), legal[sl], to_play[sl], True, num_legal=num_legal[sl])
+        parts = []
+        for g in range(2):
+            st = pipe.finish(g)
+            actions, _ = pipe.engines[g].sample_actions(1.0)
+            parts.append(({k: v.copy() for k, v in st.items()}, pipe.engines[g].noise.copy(), actions))
+        got.append(parts)
+    pipe.close()
+    for (st, noise, actions), parts in zip(want, got):
+        assert np.array_equal(noise, np.concatenate([p[1] for p in parts]))
+        assert np.array_equal(actions, np.concatenate([p[2] for p in parts]))
+        for key in ("visits", "child_value_sum", "child_prior", "root_value_sum", "max_tree_depth", "min_max"):
+            assert np.array_equal(st[key], np.concatenate([p[0][key] for p in parts])), key
