@@ -64,3 +64,20 @@ def test_host_build_returns_libm_bits(tmp_path):
     report = json.loads(proc.stdout.strip().splitlines()[-1])
     assert proc.returncode == 0 and report["log_mismatches"] == 0 and report["pow_mismatches"] == 0, proc.stdout
     assert report["pow_results_below_1e-200"] > 100000     # the scaled / subnormal tail of pow was exercised
+
+
+def test_device_dirichlet_sampler_equals_host_sampler_on_cpu(tmp_path):
+    """np_legacy_rng.h DeviceStream (what root_noise_kernel runs) built for the host: the same Dirichlet rows, word
+    counts and stream states as HostStream on this machine's libm, 50 400 rows over 400 seeds, shapes 0.03 ... 1 and
+    2 ... 121 entries (HostStream itself is pinned to numpy's vectors by fixture G7, tests/test_native_abi.py)."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "device_stream_check")
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-I", CSRC]
+    if "fma" in open("/proc/cpuinfo").read():
+        flags.append("-mfma")
+    subprocess.run([gxx] + flags + ["-o", exe, os.path.join(ROOT, "tests", "device_stream_check.cpp"), "-lm"], check=True)
+    proc = subprocess.run([exe], capture_output=True, text=True)
+    report = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert proc.returncode == 0 and report["mismatches"] == 0 and report["rows"] == 400 * 7 * 6 * 3, proc.stdout
