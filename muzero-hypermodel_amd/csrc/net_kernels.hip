@@ -581,7 +581,7 @@ extern "C" int mzmcts_conv_heads_multi(const float* const* xs, const mzmcts_head
     for (int h = 0; h < n_heads; ++h)
         if (!xs[h] || (reinterpret_cast<uintptr_t>(xs[h]) & 15u)) return MZMCTS_ERR_INVALID;
     static const bool use_mfma = std::getenv("MZ_HEADS_WAVE_PER_SAMPLE") == nullptr;
-    bool mfma = use_mfma && batch >= mz::kTileSamples;
+    bool mfma = use_mfma;      // (any batch: a sample's logits do not depend on how many samples share its launch)
     for (int h = 0; h < n_heads && mfma; ++h) mfma = mz::mfma_head_ok(heads[h]);
     if (mfma) {
         mz::MfmaHeadSet mset{};

@@ -857,13 +857,30 @@ class DeviceSelfPlay(ManyEnvLoop):
 
     def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
         """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
+        self.step_begin(on_game, on_games)
+        self.step_end(temperature, temperature_threshold, on_game, on_games)
+
+    def step_begin(self, on_game=None, on_games=None):
+        """First half of step(): queue the search of every env's current position on the engine's stream and return
+        (the GPU works; `step_end` waits).  Two actors on streams of their own alternate their halves
+        (PipelinedDeviceSelfPlay): one's host work runs under the other's search."""
         self.flush(on_game, on_games)      # first: the unfiled batch holds views of the download ring
         self._drop_batch()
         if getattr(self, "_filer_owns_rows", False):
             self._filer.store_rows(self._obs, self._act, self._rew, self._tp, self._cv, self._rv, self._len)
             self._filer_owns_rows = False
         cur = self._cur
-        self.engine.search(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True, num_legal=cur["num_legal"])
+        if self.engine._fc_model is not None:
+            self.engine.search_fused_begin(cur["obs_dev"].reshape(self.E, -1), cur["legal"], cur["to_play"], True,
+                                           num_legal=cur["num_legal"])
+        else:
+            self.engine.search_begin(self.model, cur["obs_dev"], cur["legal"], cur["to_play"], True,
+                                     num_legal=cur["num_legal"])
+
+    def step_end(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
+        """Second half of step(): wait for the search, sample the actions, step the envs, file the move."""
+        cur = self._cur
+        self.engine.readout()
         if temperature_threshold:
             # play_game: temperature only while len(action_history) < threshold (self_play.py:163-170)
             temps = numpy.where(self._len + 1 < temperature_threshold, float(temperature), 0.0)
@@ -1028,3 +1045,61 @@ class DeviceSelfPlay(ManyEnvLoop):
     def close(self):
         self.envs.close()
         self.engine.close()
+
+
+class PipelinedDeviceSelfPlay:
+    """`groups` DeviceSelfPlay actors of num_envs / groups envs each, on HIP streams of their own, alternating the halves
+    of a move (step_begin / step_end): while the host samples, steps, observes and files one group's move, the GPU
+    searches the other group's positions.  Env e keeps seed `seed + e`, so the groups together play the games one
+    DeviceSelfPlay of num_envs envs plays (tests/test_gpu_envs.py).  Callbacks see global env indices."""
+
+    def __init__(self, initial_checkpoint, game_name, config, seed, num_envs, groups=2, device=None, use_graph=True):
+        assert num_envs % groups == 0
+        self.groups, self.per_group, self.E = groups, num_envs // groups, num_envs
+        self.actors, self.streams = [], []
+        for g in range(groups):
+            actor = DeviceSelfPlay(initial_checkpoint, game_name, config, seed + g * self.per_group, self.per_group,
+                                   device=device, use_graph=use_graph)
+            stream = torch.cuda.Stream(device=actor.device)
+            actor.engine.stream = stream
+            self.actors.append(actor)
+            self.streams.append(stream)
+        self._started = [False] * groups
+
+    @property
+    def moves_played(self):
+        return sum(a.moves_played for a in self.actors)
+
+    @property
+    def games_finished(self):
+        return sum(a.games_finished for a in self.actors)
+
+    def set_weights(self, weights):
+        for a in self.actors:
+            a.set_weights(weights)
+
+    def _callbacks(self, g, on_game, on_games):
+        base = g * self.per_group
+        one = None if on_game is None else (lambda e, gh: on_game(base + e, gh))
+
+        def many(batch):
+            batch.env_index = batch.env_index + base
+            on_games(batch)
+        return one, (None if on_games is None else many)
+
+    def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
+        """One move in every env of every group (each group's search was queued during the previous call)."""
+        for g, actor in enumerate(self.actors):
+            one, many = self._callbacks(g, on_game, on_games)
+            with torch.cuda.stream(self.streams[g]):
+                if self._started[g]:
+                    actor.step_end(temperature, temperature_threshold, one, many)
+                else:
+                    actor.step_begin(one, many)
+                    actor.step_end(temperature, temperature_threshold, one, many)
+                actor.step_begin(one, many)          # the next move's search runs while the other groups are served
+                self._started[g] = True
+
+    def close(self):
+        for a in self.actors:
+            a.engine.close()

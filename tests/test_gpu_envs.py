@@ -123,6 +123,37 @@ def test_device_self_play_equals_host_env_self_play(dev, pkg):
                 assert np.array_equal(np.asarray(oa, dtype=np.float32), ob)
 
 
+def test_pipelined_device_self_play_equals_single_actor(dev, pkg):
+    """PipelinedDeviceSelfPlay (two actors of 8 envs on streams of their own, alternating the halves of a move) plays the
+    games one DeviceSelfPlay of 16 envs plays: same actions, rewards, search statistics and observations per env."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("tictactoe").MuZeroConfig()
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E, moves = 16, 14
+    out = {}
+    for kind in ("single", "pipelined"):
+        games_done = {}
+        if kind == "single":
+            actor = sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, use_graph=False)
+        else:
+            actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2, use_graph=False)
+        for _ in range(moves):
+            actor.step(1.0, None, on_game=lambda e, gh: games_done.setdefault(e, []).append(gh))
+        assert actor.moves_played == E * moves
+        actor.close()
+        out[kind] = games_done
+    assert set(out["single"]) == set(out["pipelined"]) and len(out["single"]) == E
+    for e in out["single"]:
+        assert len(out["single"][e]) == len(out["pipelined"][e])
+        for a, b in zip(out["single"][e], out["pipelined"][e]):
+            assert a.action_history == b.action_history and a.reward_history == b.reward_history
+            assert np.array_equal(np.array(a.child_visits, dtype=float), np.array(b.child_visits, dtype=float))
+            assert a.root_values == b.root_values
+            for oa, ob in zip(a.observation_history, b.observation_history):
+                assert np.array_equal(oa, ob)
+
+
 def test_device_self_play_cartpole_fused(dev, pkg):
     sp = importlib.import_module("muzero-hypermodel_amd.self_play")
     models_mod = importlib.import_module("muzero-hypermodel_amd.models")

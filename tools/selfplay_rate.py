@@ -41,6 +41,8 @@ def main():
     for kind in args.kinds.split(","):
         if kind == "host":
             actor = sp.BatchedSelfPlay({"weights": weights}, mod.Game, config, 0, args.envs)
+        elif kind == "device-pipelined":
+            actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs, groups=2)
         else:
             actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs)
             if kind == "device-batch":
