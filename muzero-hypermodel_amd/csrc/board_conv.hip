@@ -275,6 +275,28 @@ struct TowerArgs {
     int32_t n_layers;
 };
 
+// Diagnostic build only (-DMZ_TOWER_STAMPS, tools/stamp_tower.py): cycles of wave 0 of every workgroup per phase of the
+// tower kernel, summed into a debug buffer nothing else reads.  The production library never defines it.
+#ifdef MZ_TOWER_STAMPS
+static __device__ unsigned long long g_tower_stamps[16];
+#define MZ_TSTAMP_DECL unsigned long long tstamp_prev = __builtin_readcyclecounter(), tstamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MZ_TSTAMP(slot)                                                    \
+    do {                                                                   \
+        const unsigned long long now__ = __builtin_readcyclecounter();     \
+        tstamp_acc[slot] += now__ - tstamp_prev;                           \
+        tstamp_prev = now__;                                               \
+    } while (0)
+#define MZ_TSTAMP_FLUSH                                                                              \
+    do {                                                                                             \
+        if (threadIdx.x == 0)                                                                        \
+            for (int s__ = 0; s__ < 8; ++s__) atomicAdd(&g_tower_stamps[s__], tstamp_acc[s__]);      \
+    } while (0)
+#else
+#define MZ_TSTAMP_DECL
+#define MZ_TSTAMP(slot)
+#define MZ_TSTAMP_FLUSH
+#endif
+
 template <int NT, int H, int W, int SB>
 __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const float* __restrict__ x, int batch, int cin0,
                                                                        uint32_t cin0_magic, int cp0, int cp1,
@@ -296,6 +318,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
     const int buf1_at = SB * PP * cp0;                  // (offsets into lds, so that every access stays an LDS access)
+    MZ_TSTAMP_DECL
 
     // ---- zero both buffers (borders, padding channels, missing samples), then the tower's input into buffer 0 -------
     {
@@ -304,6 +327,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         for (int i = tid; i < words / 4; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    MZ_TSTAMP(0);
     {
         const int count = n_samples * cin0 * P;
         const float* src = x + static_cast<size_t>(b0) * cin0 * P;
@@ -334,6 +358,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     }
     __syncthreads();
 
+    MZ_TSTAMP(1);
     const int col_tile = wave % NT;
     const int row_group = wave / NT;
     const int i_row = lane & 15;
@@ -383,11 +408,20 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         }
         int grp_now = 0;
         for (int it = 0; it < iterations; ++it) {
+#ifdef MZ_TOWER_NO_WLOAD
+            const f32x4 bn = b;
+#else
             const f32x4 bn = wlane[static_cast<size_t>(it + 2) * 4 * COUT];
+#endif
             const int off = lds_offset();
             f32x4 an[MTW];
+#ifdef MZ_TOWER_NO_ALOAD
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) an[t] = a[t];
+#else
 #pragma unroll
             for (int t = 0; t < MTW; ++t) an[t] = reinterpret_cast<const f32x4*>(lds)[(in + pos_a[t] * CPI + off) >> 2];
+#endif
             advance();
             const int steps = (grp_now == ng - 1) ? last_steps : 4;
             grp_now = (grp_now + 1 == ng) ? 0 : grp_now + 1;
@@ -413,6 +447,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
             b1 = bn;
         }
 
+        MZ_TSTAMP(2);
         // ---- layer epilogue into the destination planes: D[row = 4 kk + r][col = lane & 15] ----------------------------
         const float sc = L.scale[n_col], sh = L.shift[n_col];
 #pragma unroll
@@ -432,7 +467,9 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                 *cell = v;
             }
         }
+        MZ_TSTAMP(3);
         __syncthreads();                                // the layer's output is complete; its input may be overwritten
+        MZ_TSTAMP(4);
 
         if (L.export_raw || L.export_unit) {
             const int out_count = n_samples * COUT * P;
@@ -474,8 +511,10 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                 }
             }
             __syncthreads();
+            MZ_TSTAMP(5);
         }
     }
+    MZ_TSTAMP_FLUSH;
 }
 
 template <int NT, int H, int W, int SB>
@@ -1015,3 +1054,14 @@ extern "C" int mzmcts_board_tower_split(const float* x, int64_t batch, int32_t c
     if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream);
     return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream);
 }
+
+#ifdef MZ_TOWER_STAMPS
+extern "C" int mzmcts_tower_stamps(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mz::g_tower_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long zeros[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mz::g_tower_stamps), zeros, sizeof(zeros)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
