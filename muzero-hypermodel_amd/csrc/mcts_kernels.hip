@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "fc_net_device.h"
@@ -325,6 +326,25 @@ __global__ __launch_bounds__(256) void gather_dynamics_input_kernel(TreeParams p
     const int row = p.H + plane;
     const float fill = static_cast<float>(action[e]) / action_space;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < row; i += gridDim.y * blockDim.x) dst[i] = i < p.H ? src[i] : fill;
+}
+
+// The same for SHORT rows (3x3 boards: 153 floats): a 256-thread block per env leaves most lanes idle and makes E tiny
+// workgroups; here a block takes `envs_per_block` consecutive envs and walks their rows as one flat, fully coalesced
+// index range (e = t / row by a multiply: exact for t < envs_per_block * row <= 4096).
+__global__ __launch_bounds__(256) void gather_dynamics_rows_kernel(TreeParams p, const int64_t* __restrict__ action,
+                                                                   float* __restrict__ out, int plane, float action_space,
+                                                                   int envs_per_block, uint32_t row_magic) {
+    const int row = p.H + plane;
+    const int e0 = blockIdx.x * envs_per_block;
+    const int envs = (p.E - e0 < envs_per_block) ? p.E - e0 : envs_per_block;
+    float* dst = out + static_cast<size_t>(e0) * row;
+    for (int t = threadIdx.x; t < envs * row; t += 256) {
+        const int le = static_cast<int>((static_cast<uint32_t>(t) * row_magic) >> 20);
+        const int i = t - le * row;
+        const int e = e0 + le;
+        dst[t] = i < p.H ? p.hidden[(static_cast<size_t>(p.leaf_parent[e]) * p.E + e) * p.H + i]
+                         : static_cast<float>(action[e]) / action_space;
+    }
 }
 
 // Contiguous slab copy (network output -> pool slab) when the caller could not write in place.
@@ -907,7 +927,15 @@ hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_
 
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
                                         hipStream_t stream) {
-    int gy = (p.H + plane + 255) / 256;
+    const int row = p.H + plane;
+    if (row <= 512) {   // short rows: several envs per block (t < 4096: the multiply-shift division by row is exact)
+        const int per_block = std::max(1, 2048 / row);
+        const uint32_t magic = ((1u << 20) + static_cast<uint32_t>(row) - 1u) / static_cast<uint32_t>(row);
+        gather_dynamics_rows_kernel<<<dim3((p.E + per_block - 1) / per_block), dim3(256), 0, stream>>>(
+            p, action, out, plane, static_cast<float>(action_space), per_block, magic);
+        return hipGetLastError();
+    }
+    int gy = (row + 255) / 256;
     if (gy > 8) gy = 8;
     gather_dynamics_input_kernel<<<dim3(p.E, gy), dim3(256), 0, stream>>>(p, action, out, plane,
                                                                            static_cast<float>(action_space));
