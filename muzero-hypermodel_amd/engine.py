@@ -141,7 +141,12 @@ class BatchedMCTS:
         _native.check(self._lib, self._h, rc)
 
     def _stream(self):
-        stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        # (while a hipGraph is being captured the launches must go to the capturing stream, which torch has made the
+        # current one -- on the engine's own stream they would run right away and be missing from every replay)
+        if self.stream is not None and not torch.cuda.is_current_stream_capturing():
+            stream = self.stream
+        else:
+            stream = torch.cuda.current_stream(self.device)
         return ctypes.c_void_p(stream.cuda_stream)
 
     # ---- RNG ------------------------------------------------------------------------------------

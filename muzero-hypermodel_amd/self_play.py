@@ -758,9 +758,11 @@ class HistoryFiler:
         addr = self._lib.mzhist_lengths(self._h)
         return numpy.ctypeslib.as_array(self._ct.cast(addr, self._ct.POINTER(self._ct.c_int32)), shape=(self.E,))
 
-    def file(self, out, legal, num_legal, num_simulations, rewards, done, obs_after, obs_next):
+    def file(self, out, legal, num_legal, num_simulations, rewards, done, obs_after, obs_next, to_play_after=None,
+             to_play_next=None):
         """out: engine.moves_collect() result (copies or ring views); rewards f32 [M,E], done u8 [M,E],
-        obs_after / obs_next f32 [M,E,...] host arrays.  Returns PackedGames of the games that ended, or None."""
+        obs_after / obs_next f32 [M,E,...] host arrays; to_play_after / to_play_next [M,E] for two-player games.
+        Returns PackedGames of the games that ended, or None."""
         ct = self._ct
         M = int(out["actions"].shape[0])
         keep = [numpy.ascontiguousarray(out["moves_done"], dtype=numpy.int32),
@@ -777,6 +779,9 @@ class HistoryFiler:
         mv.legal, mv.num_legal = keep[1].ctypes.data, keep[2].ctypes.data
         mv.rewards, mv.done, mv.obs_after, mv.obs_next = (k.ctypes.data for k in keep[3:7])
         mv.to_play_after = mv.to_play_next = None
+        if to_play_after is not None:
+            keep += [numpy.ascontiguousarray(to_play_after, dtype=numpy.int32), numpy.ascontiguousarray(to_play_next, dtype=numpy.int32)]
+            mv.to_play_after, mv.to_play_next = keep[7].ctypes.data, keep[8].ctypes.data
         n = ct.c_int32()
         if self._lib.mzhist_file(self._h, ct.byref(mv), ct.byref(n)) != 0:
             raise RuntimeError(self._lib.mzhist_last_error(self._h).decode())
@@ -866,9 +871,6 @@ class DeviceSelfPlay(ManyEnvLoop):
         (PipelinedDeviceSelfPlay): one's host work runs under the other's search."""
         self.flush(on_game, on_games)      # first: the unfiled batch holds views of the download ring
         self._drop_batch()
-        if getattr(self, "_filer_owns_rows", False):
-            self._filer.store_rows(self._obs, self._act, self._rew, self._tp, self._cv, self._rv, self._len)
-            self._filer_owns_rows = False
         cur = self._cur
         if self.engine._fc_model is not None:
             self.engine.search_fused_begin(cur["obs_dev"].reshape(self.E, -1), cur["legal"], cur["to_play"], True,
@@ -887,7 +889,7 @@ class DeviceSelfPlay(ManyEnvLoop):
         else:
             temps = numpy.full(self.E, float(temperature))
         actions, _ = self.engine.sample_actions(numpy.ascontiguousarray(temps, dtype=numpy.float64))
-        child_visits, root_values = self.engine.search_statistics()
+        stats = self.engine.stats
         reward, done = self.envs.step(actions)
         after = self._observe_host()
         reward, done = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
@@ -896,8 +898,21 @@ class DeviceSelfPlay(ManyEnvLoop):
         if over.any():
             self.envs.reset(torch.from_numpy(over.astype(numpy.uint8)).to(self.device))
             nxt = self._observe_host()
-        self._file_move(numpy.ones(self.E, dtype=bool), actions, child_visits, root_values, reward, over,
-                        after["obs"], after["to_play"], nxt["obs"], nxt["to_play"], on_game, on_games)
+        # file the move natively (include/mzhist.h, the library's worker pool): a batch of one move whose legal sets are
+        # this move's; child visits by action and root values as store_search_statistics computes them (self_play.py:497-512)
+        one = {"actions": actions.astype(numpy.int32)[None], "visits": stats["visits"][None],
+               "root_value_sum": stats["root_value_sum"][None], "moves_done": numpy.ones(self.E, dtype=numpy.int32)}
+        batch = self._history_filer().file(one, cur["legal"], cur["num_legal"], self.config.num_simulations, reward[None],
+                                           over.astype(numpy.uint8)[None], after["obs"][None], nxt["obs"][None],
+                                           to_play_after=after["to_play"][None], to_play_next=nxt["to_play"][None])
+        self._len[:] = self._filer.lengths()
+        if batch is not None:
+            self.games_finished += len(batch)
+            if on_games is not None:
+                on_games(batch)
+            if on_game is not None:
+                for i, e in enumerate(batch.env_index):
+                    on_game(int(e), batch.history(i))
         self._cur = nxt
         self.moves_played += self.E
 

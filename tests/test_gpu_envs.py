@@ -123,7 +123,8 @@ def test_device_self_play_equals_host_env_self_play(dev, pkg):
                 assert np.array_equal(np.asarray(oa, dtype=np.float32), ob)
 
 
-def test_pipelined_device_self_play_equals_single_actor(dev, pkg):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_device_self_play_equals_single_actor(dev, pkg, use_graph):
     """PipelinedDeviceSelfPlay (two actors of 8 envs on streams of their own, alternating the halves of a move) plays the
     games one DeviceSelfPlay of 16 envs plays: same actions, rewards, search statistics and observations per env."""
     sp = importlib.import_module("muzero-hypermodel_amd.self_play")
@@ -137,7 +138,8 @@ def test_pipelined_device_self_play_equals_single_actor(dev, pkg):
         if kind == "single":
             actor = sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, use_graph=False)
         else:
-            actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2, use_graph=False)
+            actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2,
+                                               use_graph=use_graph)
         for _ in range(moves):
             actor.step(1.0, None, on_game=lambda e, gh: games_done.setdefault(e, []).append(gh))
         assert actor.moves_played == E * moves

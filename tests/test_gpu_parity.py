@@ -652,7 +652,8 @@ def test_batched_self_play_cartpole_fused(eng, models_mod, pkg):
         assert set(gh.action_history[1:]) <= {0, 1} and all(r == 1.0 for r in gh.reward_history[1:])
 
 
-def test_pipelined_lockstep_groups_equal_one_engine(eng, models_mod):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_lockstep_groups_equal_one_engine(eng, models_mod, use_graph):
     """engine.PipelinedLockstep: the envs as two lock-step engines on streams of their own (one group's host work under
     the other's kernels, network replica per group) play exactly what one engine of all envs plays -- noise, visit counts,
     value sums, sampled actions -- over two consecutive moves (TicTacToe residual network, masked roots)."""
@@ -672,15 +673,15 @@ def test_pipelined_lockstep_groups_equal_one_engine(eng, models_mod):
 
     single = eng.BatchedMCTS(config, E, seeds=seeds)
     want = []
-    for _ in range(2):
+    for _ in range(4):       # (with use_graph: an eager move, the move that captures the simulation loop, two replays)
         st = single.search(model, obs, legal, to_play, True, num_legal=num_legal)
         actions, _ = single.sample_actions(1.0)
         want.append(({k: v.copy() for k, v in st.items()}, single.noise.copy(), actions))
     single.close()
 
-    pipe = eng.PipelinedLockstep(config, E, model, groups=2, seeds=seeds, use_graph=False)
+    pipe = eng.PipelinedLockstep(config, E, model, groups=2, seeds=seeds, use_graph=use_graph)
     got = []
-    for _ in range(2):
+    for _ in range(4):
         for g in range(2):
             sl = pipe.slice(g)
             pipe.begin(g, obs[sl].contiguous(), legal[sl], to_play[sl], True, num_legal=num_legal[sl])
@@ -696,3 +697,4 @@ def test_pipelined_lockstep_groups_equal_one_engine(eng, models_mod):
         assert np.array_equal(actions, np.concatenate([p[2] for p in parts]))
         for key in ("visits", "child_value_sum", "child_prior", "root_value_sum", "max_tree_depth", "min_max"):
             assert np.array_equal(st[key], np.concatenate([p[0][key] for p in parts])), key
+        assert (st["visits"].sum(axis=1) == config.num_simulations).all()
