@@ -67,9 +67,8 @@ RHO_PORT_OVER_REFERENCE = {"cartpole": 208.0}
 # 2, one engine).
 # groups: the envs of a GPU as that many engines on streams of their own (engine.PipelinedLockstep): one group's host work
 # -- readout, action sampling, the next move's checks and uploads -- runs under the other groups' kernels, and the kernels
-# of two streams fill each other's gaps: TicTacToe 65536 envs 98 -> 162 M simulations/s with two groups (four: 159 M;
-# 131072 envs: 170 M), Connect4 4096 envs 4.9 -> 5.4 M, 8192 envs 5.8 M (16384: 5.8 M), the 84x84 config 16384 envs
-# 25.1 -> 24.3 M but 32768 envs 26.7 -> 30.5 M (65536: 30.8 M).
+# of two streams fill each other's gaps: TicTacToe 65536 envs 100 -> 138 M simulations/s with two groups, Connect4 8192
+# envs 4.94 -> 5.67 M, the 84x84 config 32768 envs 26.6 -> 27.9 M.
 WORKLOADS = {
     "cartpole": dict(envs=4096, baseline_config=2, groups=2),
     "tictactoe": dict(envs=65536, baseline_config=3, groups=2),
