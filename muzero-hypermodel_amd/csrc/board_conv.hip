@@ -989,7 +989,7 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     // cost two rounds for little more than one round's work.  With few boards that choice stands (more workgroups than
     // CUs matters most); with many, SB is the count whose rows fit ONE round and whose LDS lets two or more workgroups
     // share a CU, so that one's fill / epilogue / export phases run under another's MFMAs: 12 x 9 = 108 rows = 7 tiles
-    // (measured at 65536 TicTacToe boards: SB 16 / 28 / 12 = 318 / 313 / 300 us per launch; 6x6, 16384 boards:
+    // (measured at 65536 TicTacToe boards: SB 16 / 28 / 12 / 8 = 318 / 313 / 300 / 353 us per launch; 6x6, 16384 boards:
     // SB 4 / 7 / 3 = 513 / 513 / 428 us).
     const bool many = b >= 16384;
     if (height == 6 && width == 7) {

@@ -607,6 +607,8 @@ class BatchedMCTS:
         later waits for them.  `observations` must be a resident fp32 CUDA tensor.  Several engines on streams of their
         own overlap one engine's host work (contract checks, unpacking, action sampling) with the others' kernels."""
         stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        if not (torch.is_tensor(observations) and observations.is_cuda and observations.dtype == torch.float32):
+            raise TypeError("search_begin: observations must be a resident fp32 CUDA tensor (search() converts and copies)")
         with torch.cuda.device(self.device), torch.cuda.stream(stream):
             value, reward, policy, hidden = model.initial_inference(observations)
             self.begin_search(legal_actions, to_play, add_exploration_noise, num_legal)
