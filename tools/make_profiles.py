@@ -41,7 +41,8 @@ if have("large_e_FETCH_SIZE.json") and have("large_e_WRITE_SIZE.json") and have(
         e["frac_of_8TBs"] = roof["kernels"][short]["frac_of_8TBs"]
     json.dump(out, open(os.path.join(P, f"{tag}_lockstep_pmc_large_e.json"), "w"), indent=1)
     print("   lockstep_pmc_large_e.json")
-copy("connect4_mfma_pmc.json", "connect4_mfma_pmc.json")
+for w in ("connect4", "tictactoe", "atari84"):
+    copy(f"{w}_mfma_pmc.json", f"{w}_mfma_pmc.json")
 
 # SQ-counter picture of the fused kernel: the two passes (instruction counts; waits / activity) merged per kernel
 if have("fused_sq_insts.json") and have("fused_sq_waits.json"):

@@ -46,12 +46,15 @@ fusedsq)
     $PY "$R/tools/pmc_summary.py" /tmp/sq_b --sq 50 --top 4 > "$R/gpurun_out/fused_sq_waits.json"
     ;;
 mfma)
-    # MFMA evidence for the Connect4 network path: matrix-pipe busy cycles / instruction mix per kernel
+    # MFMA evidence for the network path of the lock-step configs: matrix-pipe busy cycles / instruction mix per kernel
     cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
-        --kernel-trace -d /tmp/mfma_c4 -o c4 --output-format csv -- \
-        $PY "$R/bench.py" --workload connect4 --steps 1 --warmup 1 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 --no-graph > "$R/gpurun_out/mfma_run.log" 2>&1
-    $PY "$R/tools/pmc_summary.py" /tmp/mfma_c4 --mfma --top 8 --tail 0.5 > "$R/gpurun_out/connect4_mfma_pmc.json"
+    for w in connect4 tictactoe atari84; do
+        [ $w = atari84 ] && timeout -k 10 300 $PY "$R/bench.py" --workload atari84 --steps 1 --warmup 1 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 > /dev/null 2>&1
+        timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
+            --kernel-trace -d /tmp/mfma_$w -o $w --output-format csv -- \
+            $PY "$R/bench.py" --workload $w --groups 1 --steps 1 --warmup 1 --min-seconds 0 --cpu-seconds 0 --profile-steps 0 --no-graph > "$R/gpurun_out/mfma_run_$w.log" 2>&1
+        $PY "$R/tools/pmc_summary.py" /tmp/mfma_$w --mfma --top 8 --tail 0.5 > "$R/gpurun_out/${w}_mfma_pmc.json"
+    done
     ;;
 large)
     # lock-step tree kernels at HBM scale (2^20 trees): per-kernel time, then FETCH_SIZE / WRITE_SIZE in their own passes
