@@ -403,6 +403,25 @@ int mzmcts_board_conv_pack_split(const float *weight, void *packed, float *const
 int mzmcts_board_tower_split(const float *x, int64_t batch, int32_t cin0, int32_t const_plane, int32_t channels,
                              int32_t height, int32_t width, const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
 
+/* The dynamics + prediction towers of a simulation step reading their input straight from the search's pools instead of
+ * from an [E, channels + 1, height, width] tensor (models.py:553-568 builds it: hidden state of the leaf's parent + one
+ * plane of action / action_space; mzmcts_select_planes writes it): sample b takes pool[(parent[b] * envs + b) * hidden_floats
+ * ...] for its first `channels` planes and action[b] / action_space for the last.  mzmcts_tower_gather_args fills the
+ * descriptor from an engine after mzmcts_select (action = the batch the select wrote, dev i64[E]); split != 0 runs the
+ * two-fp16-halves tower (channels == 64), else the exact-fp32 one.  Same results as the tensor form, one launch and one
+ * round trip through HBM of the dynamics input less per simulation. */
+typedef struct mzmcts_tower_gather {
+    const float *pool;         /* hidden-state pool f32[(S+1)][envs][hidden_floats] */
+    const int32_t *parent;     /* [envs] slab of the leaf's parent */
+    const int64_t *action;     /* [envs] */
+    int64_t envs;
+    int32_t hidden_floats;     /* channels * height * width */
+    float action_space;        /* len(config.action_space) */
+} mzmcts_tower_gather;
+int mzmcts_tower_gather_args(mzmcts_engine *engine, const int64_t *action, int32_t action_space, mzmcts_tower_gather *out);
+int mzmcts_board_tower_gathered(const mzmcts_tower_gather *gather, int64_t batch, int32_t cin0, int32_t split, int32_t channels,
+                                int32_t height, int32_t width, const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 int mzmcts_set_profiling(mzmcts_engine *engine, int32_t enabled);
 /* Trees each wavefront of mzmcts_select works through (self_play.py:321-335 is one descent; the trees are independent,

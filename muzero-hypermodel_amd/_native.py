@@ -58,6 +58,12 @@ class MzTrainLossArgs(ctypes.Structure):
                                                      "grad_policy")]
 
 
+class MzTowerGather(ctypes.Structure):
+    """include/mzmcts.h mzmcts_tower_gather."""
+    _fields_ = [("pool", ctypes.c_void_p), ("parent", ctypes.c_void_p), ("action", ctypes.c_void_p),
+                ("envs", ctypes.c_int64), ("hidden_floats", ctypes.c_int32), ("action_space", ctypes.c_float)]
+
+
 class MzFcDesc(ctypes.Structure):
     _fields_ = [("observation_floats", ctypes.c_int32), ("encoding_size", ctypes.c_int32),
                 ("n_hidden", ctypes.c_int32 * 5), ("hidden", (ctypes.c_int32 * 3) * 5)]
@@ -129,6 +135,9 @@ PROTOTYPES = {
     "mzmcts_board_tower": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_split_halfs": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_board_conv_pack_split": (ctypes.c_int, [c_void, c_void, c_void] + [ctypes.c_int32] * 5 + [c_void]),
+    "mzmcts_tower_gather_args": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, ctypes.POINTER(MzTowerGather)]),
+    "mzmcts_board_tower_gathered": (ctypes.c_int, [ctypes.POINTER(MzTowerGather), ctypes.c_int64] + [ctypes.c_int32] * 5 +
+                                    [c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_tower_split": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h

@@ -258,6 +258,19 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_conv3x3_kernel(const fl
 // V; conv2 reads V and writes relu(conv * scale + shift + x) over x in U (every element is read and written by the one
 // lane that owns it).  Per layer the same exact-fp32 MFMA main loop as board_conv3x3_kernel.
 // -------------------------------------------------------------------------------------------------------------------
+// Optional input of a tower straight from the search's pools (include/mzmcts.h mzmcts_tower_gather): sample b reads the
+// hidden state of its leaf's parent, pool[(parent[b] * envs + b) * hidden + c * P + p] for its first C channels, and
+// action[b] / action_space as its last (constant) plane -- reference models.py:553-568 without the [E, C + 1, H, W]
+// tensor in between.  pool == nullptr: the tower reads x.
+struct TowerGather {
+    const float* pool;
+    const int32_t* parent;
+    const int64_t* action;
+    long long envs;
+    int hidden;
+    float action_space;
+};
+
 struct TowerLayer {
     const float* wt;        // packed weights (mzmcts_board_conv_pack)
     const float* scale;     // folded batch norm
@@ -300,7 +313,7 @@ static __device__ unsigned long long g_tower_stamps[16];
 template <int NT, int H, int W, int SB>
 __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const float* __restrict__ x, int batch, int cin0,
                                                                        uint32_t cin0_magic, int cp0, int cp1,
-                                                                       TowerArgs args) {
+                                                                       TowerArgs args, TowerGather gather) {
     constexpr int P = H * W;
     constexpr int PW = W + 1;
     constexpr int PP = (H + 2) * PW + 1;
@@ -328,7 +341,34 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     }
     __syncthreads();
     MZ_TSTAMP(0);
-    {
+    if (gather.pool) {
+        // input gathered from the hidden-state pool (+ the action plane): element i = (sample s, channel ci, position p)
+        const int count = n_samples * cin0 * P;
+        for (int i0 = tid; i0 < count; i0 += 4 * THREADS) {
+            float v[4];
+            int at[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * THREADS;
+                at[k] = -1;
+                v[k] = 0.f;
+                if (i < count) {
+                    const int p = i % P;
+                    const int sc = i / P;
+                    const int s = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin0_magic));
+                    const int ci = sc - s * cin0;
+                    const long long b = b0 + s;
+                    v[k] = (ci * P < gather.hidden)
+                               ? gather.pool[(static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden + ci * P + p]
+                               : static_cast<float>(gather.action[b]) / gather.action_space;
+                    at[k] = (s * PP + (p / W + 1) * PW + (p % W) + 1) * cp0 + ci;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (at[k] >= 0) lds[at[k]] = v[k];
+        }
+    } else {
         const int count = n_samples * cin0 * P;
         const float* src = x + static_cast<size_t>(b0) * cin0 * P;
         auto place = [&](int i, float v) {
@@ -518,7 +558,8 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
 }
 
 template <int NT, int H, int W, int SB>
-static int launch_board_tower(const float* x, int batch, int cin0, const TowerArgs& args, hipStream_t stream) {
+static int launch_board_tower(const float* x, int batch, int cin0, const TowerArgs& args, hipStream_t stream,
+                              const TowerGather& gather = TowerGather{}) {
     constexpr int PP = (H + 2) * (W + 1) + 1;
     int cp0 = conv_groups(cin0) * kConvGroup + 4;
     int cp1 = 4;
@@ -535,7 +576,7 @@ static int launch_board_tower(const float* x, int batch, int cin0, const TowerAr
                                                static_cast<int>(lds)) != hipSuccess)
         return MZMCTS_ERR_HIP;
     const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
-    kernel<<<grid, block, lds, stream>>>(x, batch, cin0, 0xFFFFFFFFu / static_cast<uint32_t>(cin0) + 1u, cp0, cp1, args);
+    kernel<<<grid, block, lds, stream>>>(x, batch, cin0, 0xFFFFFFFFu / static_cast<uint32_t>(cin0) + 1u, cp0, cp1, args, gather);
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
@@ -615,7 +656,8 @@ struct SplitArgs {
 template <int H, int W, int SB>
 __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(const float* __restrict__ x, int batch, int cin0,
                                                                              int const_plane, uint32_t cin_load_magic,
-                                                                             int cph0, int cph1, SplitArgs args) {
+                                                                             int cph0, int cph1, SplitArgs args,
+                                                                             TowerGather gather) {
     constexpr int P = H * W;
     constexpr int PW = W + 1;
     constexpr int PP = (H + 2) * PW + 1;
@@ -658,7 +700,18 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     {
         const int cin_load = cin0 - const_plane;
         const float* src = x + static_cast<size_t>(b0) * cin0 * P;
-        if (tid < SB) aconst[tid] = (const_plane && tid < n_samples) ? src[(static_cast<size_t>(tid) * cin0 + cin_load) * P] : 0.f;
+        // (gathered input: rows of the hidden-state pool, the constant plane is action / action_space)
+        auto pool_row = [&](int sidx) {
+            const long long b = b0 + sidx;
+            return gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden;
+        };
+        if (tid < SB) {
+            float plane_value = 0.f;
+            if (const_plane && tid < n_samples)
+                plane_value = gather.pool ? static_cast<float>(gather.action[b0 + tid]) / gather.action_space
+                                          : src[(static_cast<size_t>(tid) * cin0 + cin_load) * P];
+            aconst[tid] = plane_value;
+        }
         const int count = n_samples * cin_load * P;       // elements to place; sample s, channel ci, position p
         for (int i0 = tid; i0 < count; i0 += 4 * THREADS) {
             float v[4];
@@ -673,7 +726,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                     const int sc = i / P;                 // s * cin_load + ci
                     const int sidx = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin_load_magic));
                     const int ci = sc - sidx * cin_load;
-                    v[k] = src[(static_cast<size_t>(sidx) * cin0 + ci) * P + p];
+                    v[k] = gather.pool ? pool_row(sidx)[ci * P + p] : src[(static_cast<size_t>(sidx) * cin0 + ci) * P + p];
                     at[k] = (sidx * PP + plane_pos(p)) * 2 * cph0 + ci;
                 }
             }
@@ -879,7 +932,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
 
 template <int H, int W, int SB>
 static int launch_board_tower_split(const float* x, int batch, int cin0, int const_plane, const SplitArgs& args,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, const TowerGather& gather = TowerGather{}) {
     constexpr int PP = (H + 2) * (W + 1) + 1;
     int cph0 = 64 + 8, cph1 = 64 + 8;                     // outputs are 64 channels in either buffer
     for (int l = 0; l < args.n_layers; ++l) {
@@ -895,7 +948,7 @@ static int launch_board_tower_split(const float* x, int batch, int cin0, int con
     const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
     const int cin_load = cin0 - const_plane;
     kernel<<<grid, block, lds, stream>>>(x, batch, cin0, const_plane, 0xFFFFFFFFu / static_cast<uint32_t>(cin_load) + 1u, cph0,
-                                         cph1, args);
+                                         cph1, args, gather);
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
@@ -969,9 +1022,9 @@ extern "C" int mzmcts_board_conv3x3(const float* x, const float* packed, const f
     return mz::launch_board_conv<1, 3, 3, 32>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
 }
 
-extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
-                                  const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_) {
-    if (!x || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers ||
+static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64_t batch, int32_t cin0, int32_t channels,
+                            int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_) {
+    if ((!x && !gather.pool) || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers ||
         !mzmcts_board_conv_supported(cin0, channels, height, width))
         return MZMCTS_ERR_INVALID;
     mz::TowerArgs args{};
@@ -993,18 +1046,24 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
     // SB 4 / 7 / 3 = 513 / 513 / 428 us).
     const bool many = b >= 16384;
     if (height == 6 && width == 7) {
-        if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream);
-        if (many && (cin0 * 42) % 2 == 0) return mz::launch_board_tower<1, 6, 7, 6>(x, b, cin0, args, stream);
-        return mz::launch_board_tower<1, 6, 7, 4>(x, b, cin0, args, stream);
+        if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream, gather);
+        if (many && (cin0 * 42) % 2 == 0) return mz::launch_board_tower<1, 6, 7, 6>(x, b, cin0, args, stream, gather);
+        return mz::launch_board_tower<1, 6, 7, 4>(x, b, cin0, args, stream, gather);
     }
     if (height == 6 && width == 6) {
-        if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream);
-        if (many) return mz::launch_board_tower<1, 6, 6, 3>(x, b, cin0, args, stream);
-        return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream);
+        if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream, gather);
+        if (many) return mz::launch_board_tower<1, 6, 6, 3>(x, b, cin0, args, stream, gather);
+        return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream, gather);
     }
-    if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream);
-    if (many) return mz::launch_board_tower<1, 3, 3, 12>(x, b, cin0, args, stream);
-    return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream);
+    if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream, gather);
+    if (many) return mz::launch_board_tower<1, 3, 3, 12>(x, b, cin0, args, stream, gather);
+    return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream, gather);
+}
+
+extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
+                                  const mzmcts_tower_layer* layers, int32_t n_layers, void* stream) {
+    if (!x) return MZMCTS_ERR_INVALID;
+    return board_tower_impl(x, mz::TowerGather{}, batch, cin0, channels, height, width, layers, n_layers, stream);
 }
 
 extern "C" int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout) {
@@ -1027,10 +1086,10 @@ extern "C" int mzmcts_board_conv_pack_split(const float* weight, void* packed, f
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
-extern "C" int mzmcts_board_tower_split(const float* x, int64_t batch, int32_t cin0, int32_t const_plane, int32_t channels,
-                                        int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers,
-                                        void* stream_) {
-    if (!x || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers || channels != 64 ||
+static int board_tower_split_impl(const float* x, const mz::TowerGather& gather, int64_t batch, int32_t cin0,
+                                  int32_t const_plane, int32_t channels, int32_t height, int32_t width,
+                                  const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_) {
+    if ((!x && !gather.pool) || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers || channels != 64 ||
         !mzmcts_board_conv_supported(cin0, channels, height, width) || (const_plane && cin0 < 2))
         return MZMCTS_ERR_INVALID;
     mz::SplitArgs args{};
@@ -1050,9 +1109,30 @@ extern "C" int mzmcts_board_tower_split(const float* x, int64_t batch, int32_t c
     const int b = static_cast<int>(batch);
     // (4 boards per workgroup: 3 fill the MFMA rounds better -- 126 rows = 8 tiles -- and 2 let two workgroups share a
     // CU, but both measured slower at 4096 Connect4 boards: 700 / 744 / 900 us per launch for 4 / 3 / 2)
-    if (height == 6 && width == 7) return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream);
-    if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream);
-    return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream);
+    if (height == 6 && width == 7) return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream, gather);
+    if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream, gather);
+    return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream, gather);
+}
+
+extern "C" int mzmcts_board_tower_split(const float* x, int64_t batch, int32_t cin0, int32_t const_plane, int32_t channels,
+                                        int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers,
+                                        void* stream) {
+    if (!x) return MZMCTS_ERR_INVALID;
+    return board_tower_split_impl(x, mz::TowerGather{}, batch, cin0, const_plane, channels, height, width, layers, n_layers,
+                                  stream);
+}
+
+extern "C" int mzmcts_board_tower_gathered(const mzmcts_tower_gather* g, int64_t batch, int32_t cin0, int32_t split,
+                                           int32_t channels, int32_t height, int32_t width, const mzmcts_tower_layer* layers,
+                                           int32_t n_layers, void* stream) {
+    if (!g || !g->pool || !g->parent || !g->action || g->envs < batch || !(g->action_space > 0.f) ||
+        g->hidden_floats != channels * height * width || cin0 != channels + 1)
+        return MZMCTS_ERR_INVALID;
+    const mz::TowerGather gather{g->pool, g->parent, g->action, static_cast<long long>(g->envs), g->hidden_floats,
+                                 g->action_space};
+    if (split)
+        return board_tower_split_impl(nullptr, gather, batch, cin0, 1, channels, height, width, layers, n_layers, stream);
+    return board_tower_impl(nullptr, gather, batch, cin0, channels, height, width, layers, n_layers, stream);
 }
 
 #ifdef MZ_TOWER_STAMPS

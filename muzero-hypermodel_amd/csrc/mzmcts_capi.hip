@@ -350,6 +350,17 @@ int mzmcts_select(mzmcts_engine* eng, float* parent_hidden_out, int64_t* action_
     return MZMCTS_OK;
 }
 
+int mzmcts_tower_gather_args(mzmcts_engine* eng, const int64_t* action, int32_t action_space, mzmcts_tower_gather* out) {
+    if (!eng || !action || !out || action_space <= 0) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_tower_gather_args: bad argument");
+    out->pool = eng->p.hidden;
+    out->parent = eng->p.leaf_parent;
+    out->action = action;
+    out->envs = eng->p.E;
+    out->hidden_floats = eng->p.H;
+    out->action_space = static_cast<float>(action_space);
+    return MZMCTS_OK;
+}
+
 int mzmcts_select_planes(mzmcts_engine* eng, float* planes_out, int64_t* action_out, int32_t plane, int32_t action_space,
                          void* stream_) {
     if (!eng || !planes_out || !action_out) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_select_planes: null argument");

@@ -304,15 +304,37 @@ class BatchedMCTS:
     def _planes_path(self, model):
         return len(self.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes")
 
+    def _pool_path(self, model):
+        """Residual networks whose towers can read their input straight from the hidden-state pool (include/mzmcts.h
+        mzmcts_board_tower_gathered): no [E, channels + 1, h, w] tensor between the descent and the network."""
+        ok = getattr(self, "_pool_ok", None)
+        if ok is None or ok[0] is not model:
+            usable = (not self.fused_step and self._planes_path(model) and hasattr(model, "recurrent_inference_from_pool")
+                      and model.pool_towers_supported(self.E, self.device, self.state_shape))
+            self._pool_ok = ok = (model, usable)
+        return ok[1]
+
+    def tower_gather(self):
+        """The descriptor of that input after a select() (valid for this engine's lifetime)."""
+        g = getattr(self, "_gather_desc", None)
+        if g is None:
+            g = self._gather_desc = _native.MzTowerGather()
+            self._check(self._lib.mzmcts_tower_gather_args(self._h, self.batch_action.data_ptr(), self.A, ctypes.byref(g)))
+        return g
+
     def _select_for(self, model):
         """The descent of the simulation about to run (its gather feeds the network)."""
-        if self._planes_path(model):
+        if self._pool_path(model):
+            self.select(gather=False)   # the towers gather for themselves
+        elif self._planes_path(model):
             self.select_planes()     # residual networks: the gather writes the dynamics input (state planes + action plane)
         else:
             self.select()
 
     def _infer(self, model):
         slab = self.next_slab()
+        if self._pool_path(model):
+            return model.recurrent_inference_from_pool(self.tower_gather(), self.E, out_state=slab)
         if self._planes_path(model):
             return model.recurrent_inference_from_planes(self.batch_planes, out_state=slab)
         return model.recurrent_inference(self.batch_hidden.view(self.E, *self.state_shape), self.batch_action, out_state=slab)

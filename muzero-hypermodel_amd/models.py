@@ -731,17 +731,21 @@ class MuZeroResidualNetwork(AbstractNetwork):
             layers.append((block.conv2, block.bn2, 1, 1))
         return layers
 
-    def _tower(self, x, layers, exports, const_plane=False):
+    def _tower(self, x, layers, exports, const_plane=False, gather=None, shape=None, device=None):
         """Run `layers` = [(conv, bn, relu, skip)] on x in ONE launch; exports = {layer index: (raw, unit)} tensors (or
-        None) that receive that layer's output / its min-max-rescaled form.  Returns False when the tower path does
-        not apply (training, autograd, CPU, unsupported shape, activations too large for LDS): the caller then takes
-        the per-layer path."""
+        None) that receive that layer's output / its min-max-rescaled form.  With `gather` (a _native.MzTowerGather,
+        x = None, shape = (b, cin0, h, w)) the input comes straight from the search's hidden-state pool.  Returns False
+        when the tower path does not apply (training, autograd, CPU, unsupported shape, activations too large for LDS):
+        the caller then takes the per-layer path."""
         mode = os.environ.get("MZ_BOARD_CONV", "auto")
-        if (mode == "off" or os.environ.get("MZ_BOARD_TOWER", "on") == "off" or self.training or torch.is_grad_enabled()
-                or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or len(layers) > 16):
+        if mode == "off" or os.environ.get("MZ_BOARD_TOWER", "on") == "off" or self.training or torch.is_grad_enabled() \
+                or len(layers) > 16:
+            return False
+        if gather is None and (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4):
             return False
         lib = _native.load()
-        b, cin0, h, w = x.shape
+        b, cin0, h, w = shape if gather is not None else x.shape
+        device = device if gather is not None else x.device
         channels = layers[0][0].out_channels
         if not lib.mzmcts_board_conv_supported(cin0, channels, h, w):
             return False
@@ -749,7 +753,8 @@ class MuZeroResidualNetwork(AbstractNetwork):
             if not isinstance(conv, BoardConv2d) or conv.out_channels != channels or conv.kernel_size != (3, 3) \
                     or conv.stride != (1, 1) or bn.training:
                 return False
-        x = x.contiguous()
+        if gather is None:
+            x = x.contiguous()
         # 64-channel towers run on the 16-bit matrix path with every operand split into two fp16 halves (fp32-level
         # accuracy, csrc/board_conv.hip); MZ_BOARD_CONV_PRECISION=fp32 keeps the exact-fp32 MFMA form
         split = channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
@@ -768,9 +773,12 @@ class MuZeroResidualNetwork(AbstractNetwork):
                                             table.data_ptr() if table is not None else None,
                                             raw.data_ptr() if raw is not None else None,
                                             unit.data_ptr() if unit is not None else None, conv.in_channels, relu, skip, 0)
-        with torch.cuda.device(x.device):
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            if split:
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            if gather is not None:
+                rc = lib.mzmcts_board_tower_gathered(ctypes.byref(gather), b, cin0, 1 if split else 0, channels, h, w,
+                                                     ctypes.addressof(descs), len(layers), stream)
+            elif split:
                 rc = lib.mzmcts_board_tower_split(x.data_ptr(), b, cin0, 1 if const_plane else 0, channels, h, w,
                                                   ctypes.addressof(descs), len(layers), stream)
             else:
@@ -779,18 +787,19 @@ class MuZeroResidualNetwork(AbstractNetwork):
         if rc == -1:
             return False                                 # (does not fit in LDS / shape not covered)
         if rc != 0:
-            raise RuntimeError(f"mzmcts_board_tower failed ({rc}) on a tensor of shape {tuple(x.shape)}")
+            raise RuntimeError(f"mzmcts_board_tower failed ({rc}) on an input of shape {(b, cin0, h, w)}")
         return True
 
-    def _recurrent_tower(self, planes, out_state):
+    def _recurrent_tower(self, planes, out_state, gather=None, shape=None, device=None):
         """dynamics + rescale + prediction towers of recurrent_inference as one launch; None if not applicable."""
         dyn, pred = self.dynamics_network.module, self.prediction_network.module
         layers = [(dyn.conv, dyn.bn, 1, 0)] + self._block_layers(dyn.resblocks)
         last_dyn = len(layers) - 1
         layers += self._block_layers(pred.resblocks)
-        b, _, h, w = planes.shape
+        b, _, h, w = shape if gather is not None else planes.shape
+        device = device if gather is not None else planes.device
         c = dyn.conv.out_channels
-        raw = torch.empty((b, c, h, w), dtype=torch.float32, device=planes.device)
+        raw = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
         state = out_state if out_state is not None else torch.empty_like(raw)
         if not (state.is_contiguous() and state.dtype == torch.float32 and tuple(state.shape) == (b, c, h, w)):
             return None
@@ -798,9 +807,49 @@ class MuZeroResidualNetwork(AbstractNetwork):
         exports = {last_dyn: (raw, state)}
         if features is not None:
             exports[len(layers) - 1] = (features, None)
-        if not self._tower(planes, layers, exports, const_plane=True):   # (the last input plane is action / A)
-            return None
+        if not self._tower(planes, layers, exports, const_plane=True, gather=gather, shape=shape, device=device):
+            return None                                                  # (the last input plane is action / A)
         return raw, state, features if features is not None else state
+
+    def pool_towers_supported(self, batch, device, state_shape):
+        """Can recurrent_inference_from_pool serve hidden states of shape `state_shape` = (channels, h, w) (inference
+        mode, tower shapes the HIP library covers)?  The engine asks once per model."""
+        if self.training or torch.device(device).type != "cuda":
+            return False
+        if os.environ.get("MZ_BOARD_CONV", "auto") == "off" or os.environ.get("MZ_BOARD_TOWER", "on") == "off" \
+                or os.environ.get("MZ_TOWER_GATHER", "on") == "off":
+            return False
+        dyn, pred = self.dynamics_network.module, self.prediction_network.module
+        convs = [dyn.conv] + [c for blk in list(dyn.resblocks) + list(pred.resblocks) for c in (blk.conv1, blk.conv2)]
+        c = dyn.conv.out_channels
+        if len(state_shape) != 3 or state_shape[0] != c:
+            return False
+        if c == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32":
+            # measured (one box, A/B): the 16-channel towers gain from gathering for themselves (84x84 config 27.8 -> 29.0 M
+            # simulations/s, TicTacToe 138.2 -> 138.6 M), the 64-channel split tower loses (Connect4 5.63 -> 5.51 M: 10 KB
+            # of element-wise loads per sample behind a parent-index lookup are slower than the streaming gather kernel)
+            return False
+        h, w = int(state_shape[1]), int(state_shape[2])
+        lib = _native.load()
+        return (all(isinstance(conv, BoardConv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) for conv in convs)
+                and len(convs) <= 16 and bool(lib.mzmcts_board_conv_supported(c + 1, c, h, w)))
+
+    def recurrent_inference_from_pool(self, gather, batch, out_state):
+        """recurrent_inference whose dynamics input the towers gather themselves from the engine's hidden-state pool
+        (include/mzmcts.h mzmcts_board_tower_gathered; `gather` = engine.tower_gather() after a select())."""
+        c = self.dynamics_network.module.conv.out_channels
+        h, w = out_state.shape[-2], out_state.shape[-1]
+        fused = self._recurrent_tower(None, out_state, gather=gather, shape=(batch, c + 1, h, w), device=out_state.device)
+        if fused is None:
+            raise RuntimeError("recurrent_inference_from_pool: the tower launch does not cover this network "
+                               "(pool_towers_supported should have said so)")
+        raw, next_state, features = fused
+        dyn, pred = self.dynamics_network.module, self.prediction_network.module
+        reward, value, policy_logits = conv_heads_multi([
+            (raw, (dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward)),
+            (features, (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value)),
+            (features, (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy))])
+        return value, reward, policy_logits, next_state
 
     def representation(self, observation):
         return board_rescale(self.representation_network(observation))

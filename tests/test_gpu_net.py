@@ -275,3 +275,35 @@ def test_select_planes_lays_out_the_dynamics_input(pkg):
     for e in range(E):
         assert int(actions[e]) in legal[e]
     engine.close()
+
+
+@pytest.mark.parametrize("game,split", [("tictactoe", False), ("connect4", True), ("connect4", False)])
+def test_towers_gathering_from_the_pool_equal_the_planes_form(pkg, game, split, monkeypatch):
+    """mzmcts_board_tower_gathered: the dynamics + prediction towers reading the leaf parents' hidden states straight from
+    a pool (and action / A as the last plane) return the bits of the same towers run on the gathered [E, C + 1, h, w]
+    tensor (mzmcts_select_planes' layout), exact-fp32 and split-precision form."""
+    import ctypes
+    import importlib
+    from parity_helpers import synthetic_model
+    native = importlib.import_module("muzero-hypermodel_amd._native")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = importlib.import_module(f"muzero-hypermodel_amd.games.{game}").MuZeroConfig()
+    if not split:
+        monkeypatch.setenv("MZ_BOARD_CONV_PRECISION", "fp32")
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    c, (_, h, w) = config.channels, config.observation_shape
+    E, slabs, A = 70, 5, len(config.action_space)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pool = torch.rand(slabs, E, c, h, w, generator=g, device="cuda")
+    parent = torch.randint(0, slabs, (E,), generator=g, device="cuda", dtype=torch.int32)
+    action = torch.randint(0, A, (E, 1), generator=g, device="cuda", dtype=torch.int64)
+    rows = pool[parent.long(), torch.arange(E, device="cuda")]
+    planes = models_mod.state_action_planes(rows.contiguous(), action, A)     # (a true fp32 division, as the reference's CPU path)
+    with torch.no_grad():
+        want_state = torch.empty(E, c, h, w, device="cuda")
+        want = model.recurrent_inference_from_planes(planes, out_state=want_state)
+        gather = native.MzTowerGather(pool.data_ptr(), parent.data_ptr(), action.data_ptr(), E, c * h * w, float(A))
+        got_state = torch.empty(E, c, h, w, device="cuda")
+        got = model.recurrent_inference_from_pool(gather, E, out_state=got_state)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
