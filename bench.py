@@ -730,12 +730,21 @@ def network_leg(wl, device, repeats=20):
     out = {}
     with torch.no_grad():
         if len(engine.state_shape) == 3 and hasattr(model, "recurrent_inference_from_planes"):
-            planes = engine.batch_planes                     # the dynamics input the last search's gather left behind
             slab = engine.pool[1].view(engine.E, *engine.state_shape)
-            whole = lambda: model.recurrent_inference_from_planes(planes, out_state=slab)  # noqa: E731
-            if model._recurrent_tower(planes, slab) is not None:
+            if engine._pool_path(model):
+                # the towers gather their own input from the hidden-state pool (mzmcts_board_tower_gathered): what the
+                # last search's last descent left in leaf_parent / batch_action
+                c, h, w = engine.state_shape
+                shape, gather = (engine.E, c + 1, h, w), engine.tower_gather()
+                whole = lambda: model.recurrent_inference_from_pool(gather, engine.E, out_state=slab)  # noqa: E731
+                tower = lambda: model._recurrent_tower(None, slab, gather=gather, shape=shape, device=slab.device)  # noqa: E731
+            else:
+                planes = engine.batch_planes                 # the dynamics input the last search's gather left behind
+                whole = lambda: model.recurrent_inference_from_planes(planes, out_state=slab)  # noqa: E731
+                tower = lambda: model._recurrent_tower(planes, slab)  # noqa: E731
+            if tower() is not None:
                 split = wl.config.channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
-                us = _timed(lambda: model._recurrent_tower(planes, slab), device, repeats)
+                us = _timed(tower, device, repeats)
                 alg = tower_conv_flops(wl.config) * engine.E
                 executed = alg * (3 if split else 1)
                 peak = F16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
