@@ -701,9 +701,21 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         const int cin_load = cin0 - const_plane;
         const float* src = x + static_cast<size_t>(b0) * cin0 * P;
         // (gathered input: rows of the hidden-state pool, the constant plane is action / action_space)
+        // (the SB rows' addresses once per thread, up front: looked up per element, every load would wait for its
+        // parent-index load first)
+        const float* rows[SB];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) {
+            const long long b = b0 + q;
+            rows[q] = (gather.pool && q < n_samples)
+                          ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden
+                          : nullptr;
+        }
         auto pool_row = [&](int sidx) {
-            const long long b = b0 + sidx;
-            return gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden;
+            const float* r = rows[0];
+#pragma unroll
+            for (int q = 1; q < SB; ++q) r = (sidx == q) ? rows[q] : r;
+            return r;
         };
         if (tid < SB) {
             float plane_value = 0.f;

@@ -826,8 +826,9 @@ class MuZeroResidualNetwork(AbstractNetwork):
             return False
         if c == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32":
             # measured (one box, A/B): the 16-channel towers gain from gathering for themselves (84x84 config 27.8 -> 29.0 M
-            # simulations/s, TicTacToe 138.2 -> 138.6 M), the 64-channel split tower loses (Connect4 5.63 -> 5.51 M: 10 KB
-            # of element-wise loads per sample behind a parent-index lookup are slower than the streaming gather kernel)
+            # simulations/s, TicTacToe 138.2 -> 138.6 M), the 64-channel split tower loses (Connect4 5.63 -> 5.49 M, also with the
+            # rows' addresses looked up once per thread: 10 KB of element-wise loads per sample from scattered rows are
+            # slower than the streaming gather kernel)
             return False
         h, w = int(state_shape[1]), int(state_shape[2])
         lib = _native.load()
