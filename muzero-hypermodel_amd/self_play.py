@@ -1062,14 +1062,16 @@ class DeviceSelfPlay(ManyEnvLoop):
         self.engine.close()
 
 
-class PipelinedDeviceSelfPlay:
+class PipelinedDeviceSelfPlay(ManyEnvLoop):
     """`groups` DeviceSelfPlay actors of num_envs / groups envs each, on HIP streams of their own, alternating the halves
     of a move (step_begin / step_end): while the host samples, steps, observes and files one group's move, the GPU
     searches the other group's positions.  Env e keeps seed `seed + e`, so the groups together play the games one
-    DeviceSelfPlay of num_envs envs plays (tests/test_gpu_envs.py).  Callbacks see global env indices."""
+    DeviceSelfPlay of num_envs envs plays (tests/test_gpu_envs.py).  Callbacks see global env indices.  Carries the
+    reference's continuous_self_play loop (ManyEnvLoop): a weight pull reaches every group's network replica."""
 
     def __init__(self, initial_checkpoint, game_name, config, seed, num_envs, groups=2, device=None, use_graph=True):
         assert num_envs % groups == 0
+        self.config = config
         self.groups, self.per_group, self.E = groups, num_envs // groups, num_envs
         self.actors, self.streams = [], []
         for g in range(groups):
@@ -1080,6 +1082,13 @@ class PipelinedDeviceSelfPlay:
             self.actors.append(actor)
             self.streams.append(stream)
         self._started = [False] * groups
+        self.device, self.model = self.actors[0].device, self.actors[0].model   # (what ManyEnvLoop's weight pull addresses)
+
+    def _pull_weights(self, shared_storage, version):
+        ManyEnvLoop._pull_weights(self, shared_storage, version)     # group 0's model (all ranks: one flat broadcast)
+        state = self.model.state_dict()
+        for actor in self.actors[1:]:
+            actor.model.load_state_dict(state)
 
     @property
     def moves_played(self):
@@ -1093,6 +1102,11 @@ class PipelinedDeviceSelfPlay:
         for a in self.actors:
             a.set_weights(weights)
 
+    def flush(self, on_game=None, on_games=None):
+        for g, actor in enumerate(self.actors):
+            one, many = self._callbacks(g, on_game, on_games)
+            actor.flush(one, many)
+
     def _callbacks(self, g, on_game, on_games):
         base = g * self.per_group
         one = None if on_game is None else (lambda e, gh: on_game(base + e, gh))
@@ -1102,19 +1116,36 @@ class PipelinedDeviceSelfPlay:
             on_games(batch)
         return one, (None if on_games is None else many)
 
-    def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None):
-        """One move in every env of every group (each group's search was queued during the previous call)."""
+    def step(self, temperature, temperature_threshold=None, on_game=None, on_games=None, prefetch=True):
+        """One move in every env of every group (each group's search was queued during the previous call).
+        prefetch=False leaves no search queued behind (the next call then starts them): what a caller wants before it
+        changes the weights, so that no move is searched with the weights of the move before."""
+        for g, actor in enumerate(self.actors):
+            if not self._started[g]:
+                with torch.cuda.stream(self.streams[g]):
+                    actor.step_begin(*self._callbacks(g, on_game, on_games))
+                self._started[g] = True
         for g, actor in enumerate(self.actors):
             one, many = self._callbacks(g, on_game, on_games)
             with torch.cuda.stream(self.streams[g]):
-                if self._started[g]:
-                    actor.step_end(temperature, temperature_threshold, one, many)
-                else:
-                    actor.step_begin(one, many)
-                    actor.step_end(temperature, temperature_threshold, one, many)
-                actor.step_begin(one, many)          # the next move's search runs while the other groups are served
-                self._started[g] = True
+                actor.step_end(temperature, temperature_threshold, one, many)
+                self._started[g] = False
+                if prefetch:
+                    actor.step_begin(one, many)      # the next move's search runs while the other groups are served
+                    self._started[g] = True
+
+    def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
+        """ManyEnvLoop's pass; the last move of a pass queues nothing behind it (a weight pull follows)."""
+        finished = []
+        moves = 0
+        while True:
+            last = moves_per_pass is None or moves + 1 >= moves_per_pass
+            self.step(temperature, temperature_threshold, on_game=lambda e, gh: finished.append((e, gh)), prefetch=not last)
+            moves += 1
+            if (moves_per_pass is None and finished) or (moves_per_pass is not None and moves >= moves_per_pass):
+                return finished
 
     def close(self):
+        torch.cuda.synchronize(self.device)      # (a queued search may still be running)
         for a in self.actors:
-            a.engine.close()
+            a.close()

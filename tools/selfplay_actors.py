@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--passes", type=int, default=10)
     ap.add_argument("--moves-per-pass", type=int, default=4)
+    ap.add_argument("--groups", type=int, default=1,
+                    help="board games: engine groups per actor on streams of their own (PipelinedDeviceSelfPlay: pays from tens of thousands of envs per GPU on); 1 = one engine")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         bench = importlib.import_module("bench")
@@ -90,7 +92,11 @@ def main():
         weights = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(template, 0).items()}
     storage = Storage(weights, args.passes) if rank == 0 else None
     replay = Replay(storage)
-    actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, config.seed + rank * args.envs, args.envs, device=device)
+    if args.groups > 1 and config.network != "fullyconnected":
+        actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, args.game, config, config.seed + rank * args.envs, args.envs,
+                                           groups=args.groups, device=device)
+    else:
+        actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, config.seed + rank * args.envs, args.envs, device=device)
 
     play_pass = actor._play_pass
 
