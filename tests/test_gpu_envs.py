@@ -213,3 +213,26 @@ def test_device_self_play_in_move_batches_equals_move_by_move(dev, pkg):
             assert all(np.array_equal(x, y) for x, y in zip(ga.observation_history, gb.observation_history))
             compared += 1
     assert compared >= E // 2
+
+
+def test_pipelined_actor_passes_with_weight_changes_equal_single_actor(dev, pkg):
+    """ManyEnvLoop passes (moves_per_pass = 3) with a weight change between them: the pipelined actor leaves no search
+    queued across the change, so both actors search every move with the same weights and finish the same games."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("tictactoe").MuZeroConfig()
+    _, w0 = synthetic_model(models_mod, config, "cpu", seed=0)
+    _, w1 = synthetic_model(models_mod, config, "cpu", seed=1)
+    out = {}
+    for kind in ("single", "pipelined"):
+        if kind == "single":
+            actor = sp.DeviceSelfPlay({"weights": w0}, "tictactoe", config, 0, 32, use_graph=False)
+        else:
+            actor = sp.PipelinedDeviceSelfPlay({"weights": w0}, "tictactoe", config, 0, 32, groups=2, use_graph=True)
+        finished = []
+        for weights in (w0, w1, w0, w1):
+            actor.set_weights(weights)
+            finished += actor._play_pass(1.0, None, 3)
+        actor.close()
+        out[kind] = sorted((e, tuple(gh.action_history), tuple(gh.root_values)) for e, gh in finished)
+    assert len(out["single"]) > 20 and out["single"] == out["pipelined"]
