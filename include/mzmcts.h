@@ -298,6 +298,19 @@ int mzmcts_moves_predraw_next(mzmcts_engine *engine, int32_t n_moves, const int3
 int mzmcts_moves_submit_next(mzmcts_engine *engine, void *stream);
 /* Drop a pre-drawn batch that will not be run: the RNG mirror goes back to where the device copy stands. */
 int mzmcts_moves_discard_next(mzmcts_engine *engine);
+/* A batch whose inputs live on the DEVICE, for games whose legal action sets change from move to move (board games):
+ * legal_actions i32[E][A], num_legal i32[E], to_play i32[E] are device arrays the caller's environment kernels
+ * (include/mzenv.h mzenv_advance) rewrite between the moves of the batch, on the same stream; every move's search reads
+ * them as they are when it runs.  The exploration noise is drawn on the device (numpy.random.dirichlet on each tree's own
+ * stream, 0 < root_dirichlet_alpha <= 1), because the length of a move's noise row -- its legal count -- is not known
+ * to the host before the moves before it have been played; nothing is pre-drawn, nothing can stall.  temperature: host
+ * f64[E] (0, inf or 1/k).  Then mzmcts_moves_enqueue per move and mzmcts_moves_collect as for a host-input batch (the
+ * mirrors of the RNG streams step over every word the batch consumed); mzmcts_moves_inputs afterwards returns what each
+ * move was searched with: num_legal i32[M][E], legal i32[M][E][A] (child slot -> action), to_play i32[M][E] (any NULL). */
+int mzmcts_moves_prepare_device(mzmcts_engine *engine, int32_t n_moves, const int32_t *legal_actions,
+                                const int32_t *num_legal, const int32_t *to_play, int32_t add_exploration_noise,
+                                const double *temperature, void *stream);
+int mzmcts_moves_inputs(mzmcts_engine *engine, int32_t *num_legal, int32_t *legal_actions, int32_t *to_play);
 int mzmcts_moves_enqueue(mzmcts_engine *engine, const float *observations, void *stream);
 const int32_t *mzmcts_moves_actions(mzmcts_engine *engine, int32_t move);
 int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *actions, int32_t *visits,

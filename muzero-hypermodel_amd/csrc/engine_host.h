@@ -54,6 +54,9 @@ hipError_t launch_search_fused_fc(const TreeParams& p, const FcNet& net, const F
 hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_t* action_out, int queue_trees,
                          hipStream_t stream, const LaunchTiming* timing);
 hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_t stream);
+hipError_t launch_move_inputs(const TreeParams& p, const uint32_t* rng_skip, const uint8_t* stall, const int32_t* move_limit,
+                              int move_index, bool draw_noise, int32_t* nlegal_out, int32_t* to_play_out, uint32_t* words_out,
+                              int32_t* legal_out, hipStream_t stream);
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
                                         hipStream_t stream);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -307,6 +310,13 @@ struct mzmcts_engine {
         uint8_t *h_out = nullptr, *d_out = nullptr;  // [M] output blocks
         uint8_t* d_stall = nullptr;
         hipEvent_t done = nullptr;
+        // batches whose inputs live on the device (mzmcts_moves_prepare_device): the legal sets / players to move the
+        // caller's kernels rewrite between the moves, and per move what the search was run with (for the host afterwards)
+        bool device_inputs = false;
+        const int32_t *dev_legal = nullptr, *dev_nlegal = nullptr, *dev_to_play = nullptr;
+        int inputs_capacity = 0;
+        size_t in2_stride = 0, o2_nlegal = 0, o2_to_play = 0, o2_words = 0, o2_legal = 0;
+        uint8_t *d_inputs = nullptr, *h_inputs = nullptr;   // [M] blocks: nlegal i32[E] | to_play i32[E] | noise words u32[E] | legal i32[E][A]
     } batch;
 
     // pending asynchronous readout (mzmcts_readout_begin)

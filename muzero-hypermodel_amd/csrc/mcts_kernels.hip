@@ -582,6 +582,44 @@ __global__ __launch_bounds__(kThreads) void root_noise_kernel(TreeParams p, uint
     p.noise_words[e] = stream.words;
 }
 
+// One move of a batch whose inputs live on the device (mzmcts_moves_prepare_device): records what the coming search is
+// run with -- legal set, player to move: the caller's environment kernels will overwrite them for the next move -- and, for
+// the envs that will be searched (active, not stalled, inside their move limit: the conditions of move_stalled), steps
+// over the host's pending words and draws the exploration noise as root_noise_kernel does.
+__global__ __launch_bounds__(kThreads) void move_inputs_kernel(TreeParams p, const uint32_t* __restrict__ rng_skip,
+                                                               const uint8_t* __restrict__ stall,
+                                                               const int32_t* __restrict__ move_limit, int move_index,
+                                                               int draw_noise, int32_t* __restrict__ nlegal_out,
+                                                               int32_t* __restrict__ to_play_out,
+                                                               uint32_t* __restrict__ words_out,
+                                                               int32_t* __restrict__ legal_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const int n = p.root_children[e];
+    nlegal_out[e] = n;
+    to_play_out[e] = p.root_to_play[e];
+    for (int i = 0; i < p.A; ++i) legal_out[static_cast<size_t>(e) * p.A + i] = p.root_action[static_cast<size_t>(e) * p.A + i];
+    words_out[e] = 0u;
+    double* row = p.noise_rows + static_cast<size_t>(e) * p.A;
+    for (int i = 0; i < p.A; ++i) row[i] = 0.0;
+    if (n == 0 || (stall && stall[e]) || (move_limit && move_index >= move_limit[e])) return;
+    uint32_t* key = p.mt_key + static_cast<size_t>(e) * kMtN;
+    int32_t pos = p.mt_pos[e];
+    const uint32_t skip = rng_skip ? rng_skip[e] : 0u;
+    for (uint32_t i = 0; i < skip; ++i) (void)mt_next(key, &pos);
+    if (draw_noise) {
+        __shared__ uint32_t window[kThreads][kNoiseWindow + 1];
+        const int ahead = (kMtN - pos < kNoiseWindow) ? kMtN - pos : kNoiseWindow;
+#pragma unroll 8
+        for (int i = 0; i < ahead; ++i) window[threadIdx.x][i] = key[pos + i];
+        DeviceStream stream{key, pos, 0u, window[threadIdx.x], pos, pos + (ahead > 0 ? ahead : 0)};
+        stream.dirichlet(p.noise_alpha, n, row);
+        pos = stream.pos;
+        words_out[e] = stream.words;
+    }
+    p.mt_pos[e] = pos;
+}
+
 // numpy.random.seed(seeds[e]) for every stream, on the device copy.
 __global__ __launch_bounds__(256) void seed_streams_kernel(uint32_t* __restrict__ keys, int32_t* __restrict__ pos,
                                                            const uint32_t* __restrict__ seeds, int E) {
@@ -930,6 +968,14 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
 
 hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_t stream) {
     root_noise_kernel<<<dim3((p.E + kThreads - 1) / kThreads), dim3(kThreads), 0, stream>>>(p, rng_skip);
+    return hipGetLastError();
+}
+
+hipError_t launch_move_inputs(const TreeParams& p, const uint32_t* rng_skip, const uint8_t* stall, const int32_t* move_limit,
+                              int move_index, bool draw_noise, int32_t* nlegal_out, int32_t* to_play_out, uint32_t* words_out,
+                              int32_t* legal_out, hipStream_t stream) {
+    move_inputs_kernel<<<dim3((p.E + kThreads - 1) / kThreads), dim3(kThreads), 0, stream>>>(
+        p, rng_skip, stall, move_limit, move_index, draw_noise ? 1 : 0, nlegal_out, to_play_out, words_out, legal_out);
     return hipGetLastError();
 }
 

@@ -236,6 +236,7 @@ int mzmcts_moves_prepare(mzmcts_engine* eng, int32_t n_moves, const int32_t* leg
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare: collect the previous batch first");
     if ((rc = ensure_batch_capacity(eng, n_moves))) return rc;
     ChainSet& c = b.set[b.cur];
+    b.device_inputs = false;
     fill_set(eng, c, n_moves, legal, num_legal, to_play, add_noise, temperature);
     eng->for_each_env([&](int lo, int hi) {
         for (int e = lo; e < hi; ++e) draw_env_rows(eng, c, e, false, nullptr);
@@ -245,12 +246,102 @@ int mzmcts_moves_prepare(mzmcts_engine* eng, int32_t n_moves, const int32_t* leg
     return upload_set(eng, c, static_cast<hipStream_t>(stream_));
 }
 
+// ---- batches whose inputs live on the device -------------------------------------------------------------------------
+// (games whose legal action sets change from move to move: the host cannot know a move's legal set -- nor, therefore,
+// the length of its Dirichlet row -- before the moves before it have been played on the device)
+static int ensure_inputs_capacity(mzmcts_engine* eng, int n_moves) {
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (n_moves <= b.inputs_capacity) return 0;
+    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A);
+    auto align = [](size_t v) { return (v + 255) / 256 * 256; };
+    b.o2_nlegal = 0;
+    b.o2_to_play = align(sizeof(int32_t) * E);
+    b.o2_words = align(b.o2_to_play + sizeof(int32_t) * E);
+    b.o2_legal = align(b.o2_words + sizeof(uint32_t) * E);
+    b.in2_stride = align(b.o2_legal + sizeof(int32_t) * E * A);
+    int rc;
+    if ((rc = dev_alloc(eng, &b.d_inputs, b.in2_stride * static_cast<size_t>(n_moves)))) return rc;
+    if ((rc = pinned_alloc(eng, &b.h_inputs, b.in2_stride * static_cast<size_t>(n_moves)))) return rc;
+    b.inputs_capacity = n_moves;
+    return 0;
+}
+
+int mzmcts_moves_prepare_device(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal_dev, const int32_t* num_legal_dev,
+                                const int32_t* to_play_dev, int32_t add_noise, const double* temperature, void* stream_) {
+    if (!eng || !legal_dev || !num_legal_dev || !to_play_dev || !temperature)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: null argument");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: call mzmcts_fc_configure first");
+    if (n_moves < 1 || n_moves > 4096) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: n_moves out of range");
+    if (add_noise && !(eng->cfg.root_dirichlet_alpha > 0.0 && eng->cfg.root_dirichlet_alpha <= 1.0))
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: the device draws Dirichlet noise for 0 < "
+                                             "root_dirichlet_alpha <= 1 only");
+    const int E = eng->p.E;
+    for (int e = 0; e < E; ++e) {
+        const double t = temperature[e];
+        if (!(t == 0.0 || std::isinf(t) || (mz::exact_inverse_temperature(t) && std::pow(eng->p.S, 1.0 / t) < 9.0e15)))
+            return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: the device samples actions at temperature 0, "
+                                                 "inf or 1/k, k = 1..4, only");
+    }
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (b.in_flight || b.set[b.cur ^ 1].drawn)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: collect the previous batch first");
+    int rc;
+    if ((rc = ensure_batch_capacity(eng, n_moves))) return rc;
+    if ((rc = ensure_inputs_capacity(eng, n_moves))) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ChainSet& c = b.set[b.cur];
+    c.n_moves = n_moves;
+    c.add_noise = add_noise != 0;
+    std::memcpy(c.temperature.data(), temperature, sizeof(double) * E);
+    // control block: words the mirrors consumed since the device copies last moved (move 0 steps over them), the
+    // temperatures, a move limit of the whole batch; no noise rows, no assumed tie-break counts
+    uint32_t* skip = reinterpret_cast<uint32_t*>(c.h_in + b.o_skip);
+    std::memset(skip, 0, sizeof(uint32_t) * static_cast<size_t>(n_moves) * E);
+    for (int e = 0; e < E; ++e) {
+        skip[e] = eng->lag[e];
+        eng->lag[e] = 0;
+        reinterpret_cast<int32_t*>(c.h_in + b.o_limit)[e] = n_moves;
+        reinterpret_cast<uint32_t*>(c.h_in + b.o_expect)[e] = 0u;
+    }
+    std::memcpy(c.h_in + b.o_temp, temperature, sizeof(double) * E);
+    MZ_HIP(eng, hipMemcpyAsync(b.d_in + b.o_skip, c.h_in + b.o_skip, b.in_bytes - b.o_skip, hipMemcpyHostToDevice, stream));
+    MZ_HIP(eng, hipMemsetAsync(b.d_stall, 0, static_cast<size_t>(E), stream));
+    b.enqueued = 0;
+    b.in_flight = true;
+    b.device_inputs = true;
+    b.dev_legal = legal_dev;
+    b.dev_nlegal = num_legal_dev;
+    b.dev_to_play = to_play_dev;
+    c.drawn = true;
+    c.speculative = false;
+    eng->search_begun = false;
+    eng->roots_ready = false;
+    eng->have_readout = false;
+    return MZMCTS_OK;
+}
+
+int mzmcts_moves_inputs(mzmcts_engine* eng, int32_t* num_legal, int32_t* legal, int32_t* to_play) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.device_inputs || b.in_flight)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_inputs: collect a mzmcts_moves_prepare_device batch first");
+    const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A);
+    for (int m = 0; m < b.enqueued; ++m) {
+        const uint8_t* blk = b.h_inputs + b.in2_stride * static_cast<size_t>(m);
+        if (num_legal) std::memcpy(num_legal + m * E, blk + b.o2_nlegal, sizeof(int32_t) * E);
+        if (to_play) std::memcpy(to_play + m * E, blk + b.o2_to_play, sizeof(int32_t) * E);
+        if (legal) std::memcpy(legal + m * E * A, blk + b.o2_legal, sizeof(int32_t) * E * A);
+    }
+    return MZMCTS_OK;
+}
+
 int mzmcts_moves_predraw_next(mzmcts_engine* eng, int32_t n_moves, const int32_t* legal, const int32_t* num_legal,
                               const int32_t* to_play, int32_t add_noise, const double* temperature) {
     int rc = check_move_inputs(eng, n_moves, legal, num_legal, to_play, temperature, "mzmcts_moves_predraw_next");
     if (rc) return rc;
     mzmcts_engine::MoveBatch& b = eng->batch;
     if (!b.in_flight) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: no batch in flight (use mzmcts_moves_prepare)");
+    if (b.device_inputs) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: a device-input batch draws its noise on the device");
     if (b.set[b.cur ^ 1].drawn) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: the next batch is already drawn");
     if (n_moves > b.capacity)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_predraw_next: larger than the batch in flight (its buffers are in use)");
@@ -309,11 +400,32 @@ int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* st
     mz::MoveCtl ctl{};
     ctl.noise = c.add_noise ? reinterpret_cast<const double*>(b.d_in) + static_cast<size_t>(m) * E * A : nullptr;
     ctl.rng_skip = reinterpret_cast<const uint32_t*>(b.d_in + b.o_skip) + static_cast<size_t>(m) * E;
+    const int32_t *host_legal = eng->p.root_action, *host_nlegal = eng->p.root_children, *host_to_play = eng->p.root_to_play;
+    if (b.device_inputs) {
+        // the search reads the caller's device arrays; first a small kernel records them for the host, steps over the
+        // mirrors' pending words and draws the noise row (of this move's legal count) on the device
+        eng->p.root_action = const_cast<int32_t*>(b.dev_legal);
+        eng->p.root_children = const_cast<int32_t*>(b.dev_nlegal);
+        eng->p.root_to_play = const_cast<int32_t*>(b.dev_to_play);
+        uint8_t* blk = b.d_inputs + b.in2_stride * static_cast<size_t>(m);
+        hipError_t err = mz::launch_move_inputs(eng->p, ctl.rng_skip, b.d_stall, reinterpret_cast<const int32_t*>(b.d_in + b.o_limit), m,
+                                                c.add_noise, reinterpret_cast<int32_t*>(blk + b.o2_nlegal),
+                                                reinterpret_cast<int32_t*>(blk + b.o2_to_play),
+                                                reinterpret_cast<uint32_t*>(blk + b.o2_words),
+                                                reinterpret_cast<int32_t*>(blk + b.o2_legal), stream);
+        if (err != hipSuccess) {
+            eng->p.root_action = const_cast<int32_t*>(host_legal), eng->p.root_children = const_cast<int32_t*>(host_nlegal);
+            eng->p.root_to_play = const_cast<int32_t*>(host_to_play);
+            return hip_fail(eng, err, "move_inputs_kernel");
+        }
+        ctl.noise = c.add_noise ? eng->p.noise_rows : nullptr;
+        ctl.rng_skip = nullptr;
+    }
     ctl.temperature = reinterpret_cast<const double*>(b.d_in + b.o_temp);
     ctl.move_limit = reinterpret_cast<const int32_t*>(b.d_in + b.o_limit);
     ctl.stall = b.d_stall;
     ctl.move_index = m;
-    ctl.expected_ties = m > 0 ? reinterpret_cast<const uint32_t*>(b.d_in + b.o_expect) : nullptr;
+    ctl.expected_ties = (m > 0 && !b.device_inputs) ? reinterpret_cast<const uint32_t*>(b.d_in + b.o_expect) : nullptr;
     ctl.actions = reinterpret_cast<int32_t*>(out + b.o_actions);
     ctl.visits = reinterpret_cast<int32_t*>(out + b.o_visits);
     ctl.root_value_sum = reinterpret_cast<double*>(out + b.o_rvs);
@@ -323,6 +435,9 @@ int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* st
     ctl.sample_words = reinterpret_cast<uint32_t*>(out + b.o_sample);
     ctl.depth_sum = reinterpret_cast<int32_t*>(out + b.o_dsum);
     int rc = mzhost_launch_fused_move(eng, observations, ctl, true, stream);
+    eng->p.root_action = const_cast<int32_t*>(host_legal);
+    eng->p.root_children = const_cast<int32_t*>(host_nlegal);
+    eng->p.root_to_play = const_cast<int32_t*>(host_to_play);
     if (rc) return rc;
     b.enqueued = m + 1;
     return MZMCTS_OK;
@@ -363,6 +478,8 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
     MZ_HIP(eng, hipEventSynchronize(b.done));
     const double t_kernels = trace ? now() : 0.0;
     if (M > 0) MZ_HIP(eng, hipMemcpyAsync(b.h_out, b.d_out, b.out_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
+    if (M > 0 && b.device_inputs)
+        MZ_HIP(eng, hipMemcpyAsync(b.h_inputs, b.d_inputs, b.in2_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, eng->p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipEventRecord(b.done, stream));
     MZ_HIP(eng, hipEventSynchronize(b.done));
@@ -378,6 +495,47 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
     auto block = [&](int m, size_t off) { return b.h_out + b.out_stride * static_cast<size_t>(m) + off; };
     ChainSet* sets[2] = {&c, next.drawn ? &next : nullptr};
     std::atomic<int64_t> played_total{0}, depth_total{0};
+    if (b.device_inputs) {
+        // nothing was drawn ahead on the mirrors: every word of the batch -- noise, tie-breaks, action sampling -- was
+        // consumed on the device copies; the mirrors step over them
+        auto inputs = [&](int m, size_t off) { return b.h_inputs + b.in2_stride * static_cast<size_t>(m) + off; };
+        eng->for_each_env([&](int lo, int hi) {
+            int64_t local = 0, local_depth = 0;
+            for (int e = lo; e < hi; ++e) {
+                int k = 0;
+                while (k < M && reinterpret_cast<const int32_t*>(block(k, b.o_actions))[e] >= 0) ++k;
+                if (moves_done) moves_done[e] = k;
+                uint64_t words = 0;
+                for (int m = 0; m < M; ++m) {
+                    const bool live = m < k;
+                    const size_t me = static_cast<size_t>(m) * E + e;
+                    if (actions) actions[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_actions))[e] : -1;
+                    if (visits)
+                        for (int i = 0; i < A; ++i)
+                            visits[me * A + i] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_visits))[static_cast<size_t>(e) * A + i] : 0;
+                    if (root_value_sum) root_value_sum[me] = live ? reinterpret_cast<const double*>(block(m, b.o_rvs))[e] : 0.0;
+                    if (root_predicted) root_predicted[me] = live ? reinterpret_cast<const float*>(block(m, b.o_pred))[e] : 0.f;
+                    if (max_depth) max_depth[me] = live ? reinterpret_cast<const int32_t*>(block(m, b.o_depth))[e] : 0;
+                    if (live) {
+                        words += reinterpret_cast<const uint32_t*>(inputs(m, b.o2_words))[e];
+                        words += reinterpret_cast<const uint32_t*>(block(m, b.o_ties))[e];
+                        words += reinterpret_cast<const uint32_t*>(block(m, b.o_sample))[e];
+                        if (eng->profiling) local_depth += reinterpret_cast<const int32_t*>(block(m, b.o_dsum))[e];
+                    }
+                }
+                // (an env that searched nothing kept the pending words of its mirror: they were not stepped over)
+                if (k == 0) eng->lag[e] += reinterpret_cast<const uint32_t*>(c.h_in + b.o_skip)[e];
+                eng->streams[e].skip(words);
+                local += k;
+            }
+            played_total.fetch_add(local, std::memory_order_relaxed);
+            depth_total.fetch_add(local_depth, std::memory_order_relaxed);
+        });
+        c.drawn = false;
+        eng->prof.simulations += played_total.load() * eng->p.S;
+        eng->prof.select_depth_sum += depth_total.load();
+        return MZMCTS_OK;
+    }
     eng->for_each_env([&](int lo, int hi) {
         int64_t local = 0, local_depth = 0;
         for (int e = lo; e < hi; ++e) {

@@ -541,6 +541,28 @@ class BatchedMCTS:
         """Drop a pre-drawn batch that will not be run (the RNG mirror goes back)."""
         self._check(self._lib.mzmcts_moves_discard_next(self._h))
 
+    def moves_prepare_device(self, n_moves, legal_dev, num_legal_dev, to_play_dev, temperature, add_exploration_noise=True):
+        """A batch of `n_moves` searches whose legal sets / players to move are DEVICE tensors (int32 [E, A], [E], [E])
+        that the caller's environment kernels rewrite between the moves (games.device.DeviceEnvs.advance): board games.
+        The exploration noise is drawn on the device; nothing about a move has to be known to the host in advance."""
+        for t, shape in ((legal_dev, (self.E, self.A)), (num_legal_dev, (self.E,)), (to_play_dev, (self.E,))):
+            assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape
+        temps = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
+        self._batch_keep = []
+        self._batch_inputs_keep = (legal_dev, num_legal_dev, to_play_dev)
+        self._check(self._lib.mzmcts_moves_prepare_device(self._h, int(n_moves), legal_dev.data_ptr(), num_legal_dev.data_ptr(),
+                                                          to_play_dev.data_ptr(), 1 if add_exploration_noise else 0,
+                                                          ptr(temps, c_f64_p), self._stream()))
+
+    def moves_inputs(self, n_moves):
+        """What each move of the collected device-input batch was searched with: dict(num_legal [M, E], legal [M, E, A]
+        (child slot -> action), to_play [M, E])."""
+        out = dict(num_legal=np.zeros((n_moves, self.E), np.int32), legal=np.zeros((n_moves, self.E, self.A), np.int32),
+                   to_play=np.zeros((n_moves, self.E), np.int32))
+        self._check(self._lib.mzmcts_moves_inputs(self._h, ptr(out["num_legal"], c_i32_p), ptr(out["legal"], c_i32_p),
+                                                  ptr(out["to_play"], c_i32_p)))
+        return out
+
     def moves_enqueue(self, observations):
         """Queue the next search of the prepared batch; `observations`: resident fp32 CUDA tensor [E, obs]."""
         assert observations.is_cuda and observations.dtype == torch.float32 and observations.is_contiguous()
