@@ -951,17 +951,18 @@ class DeviceSelfPlay(ManyEnvLoop):
         """`n_moves` moves of every env with no host round trip in between: search (which samples the action),
         env step, terminal observation, reset of finished envs, next observation -- all queued on one stream;
         the exploration noise of the whole batch is drawn up front (and the next batch's while this one runs).
-        Needs a game whose legal action set never changes (CartPole) and a fully-connected network.
+        Needs a fully-connected network.  Games whose legal action set changes (board games) take the device-input
+        form of the batch (_play_moves_device_inputs).
         An env may come back with fewer than n_moves moves played (it plays the rest next time)."""
         E, eng, envs, cfg = self.E, self.engine, self.envs, self.config
         if cfg.temperature_threshold:
             # play_game drops to temperature 0 once len(action_history) reaches the threshold (self_play.py:163-170):
             # a per-env, per-move switch the batch's single temperature row cannot express
             raise NotImplementedError("play_moves does not apply config.temperature_threshold; use step()")
-        if not getattr(envs, "constant_legal_actions", False):
-            raise NotImplementedError("play_moves needs a game whose legal action set never changes")
         if cfg.max_moves < envs.max_episode_steps:
             raise NotImplementedError("play_moves ends games where the environment does; max_moves is shorter")
+        if not getattr(envs, "constant_legal_actions", False):
+            return self._play_moves_device_inputs(n_moves, temperature, on_game, on_games)
         cur = self._cur
         params = (int(n_moves), float(temperature))
         if getattr(self, "_batch_ready", None) != params:
@@ -993,11 +994,57 @@ class DeviceSelfPlay(ManyEnvLoop):
         self.moves_played += int(out["moves_done"].sum())
         return out["moves_done"].copy()
 
+    def _play_moves_device_inputs(self, n_moves, temperature, on_game, on_games):
+        """play_moves for games whose legal action set changes with every move (board games): the searches read the
+        legal sets and players to move from the environment kernels' device outputs and draw their exploration noise
+        on the device (engine.moves_prepare_device), so a whole batch -- games ending and restarting inside it -- is
+        queued without the host; afterwards every move is filed with the legal set it was searched with."""
+        E, eng, envs = self.E, self.engine, self.envs
+        if eng._fc_model is None:
+            raise NotImplementedError("play_moves runs the fused whole-move search: a fully-connected network")
+        self.flush(on_game, on_games)
+        self._drop_batch()
+        cur = self._cur
+        eng.moves_prepare_device(n_moves, envs.legal, envs.num_legal, envs.to_play, temperature, True)
+        ring = self._move_ring(n_moves)
+        obs_in = cur["obs_dev"]
+        for m in range(n_moves):
+            eng.moves_enqueue(obs_in.reshape(E, -1).contiguous())
+            obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
+                                  ring["obs_next"][m])
+        out = eng.moves_collect()
+        inputs = eng.moves_inputs(n_moves)
+        host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
+        last_to_play = envs.to_play.cpu().numpy()
+        two_players = len(self.config.players) > 1
+        filer = self._history_filer()
+        for m in range(n_moves):
+            played = (out["moves_done"] > m).astype(numpy.int32)
+            to_play_after = (1 - inputs["to_play"][m]) if two_players else numpy.zeros(E, numpy.int32)
+            to_play_next = inputs["to_play"][m + 1] if m + 1 < n_moves else last_to_play
+            one = {"actions": out["actions"][m][None], "visits": out["visits"][m][None],
+                   "root_value_sum": out["root_value_sum"][m][None], "moves_done": played}
+            batch = filer.file(one, inputs["legal"][m], inputs["num_legal"][m], self.config.num_simulations,
+                               host["reward"][m][None], host["done"][m][None], host["obs_after"][m][None],
+                               host["obs_next"][m][None], to_play_after=to_play_after[None], to_play_next=to_play_next[None])
+            if batch is not None:
+                self.games_finished += len(batch)
+                if on_games is not None:
+                    on_games(batch)
+                if on_game is not None:
+                    for i, e in enumerate(batch.env_index):
+                        on_game(int(e), batch.history(i))
+        self._len[:] = filer.lengths()
+        nxt = self._observe_host()                       # (the envs' current state: what the next step / batch searches)
+        self._cur = nxt
+        self.moves_played += int(out["moves_done"].sum())
+        return out["moves_done"].copy()
+
     def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
         """ManyEnvLoop's pass: whole move batches on the device when the game, the network and the temperature allow
         it (play_moves), else one move at a time (step)."""
         batchable = (moves_per_pass is not None and not temperature_threshold and not self.config.temperature_threshold
-                     and getattr(self.envs, "constant_legal_actions", False) and self.engine._fc_model is not None
+                     and self.engine._fc_model is not None
                      and self.config.max_moves >= self.envs.max_episode_steps
                      and (temperature == 0 or _native.exact_inverse_temperature(temperature)))
         if not batchable:

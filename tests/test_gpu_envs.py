@@ -215,6 +215,58 @@ def test_device_self_play_in_move_batches_equals_move_by_move(dev, pkg):
     assert compared >= E // 2
 
 
+def test_board_game_self_play_in_move_batches_equals_move_by_move(dev, pkg):
+    """play_moves on a game whose legal action set changes with every move (TicTacToe, fully-connected network): the
+    batch reads legal sets and players to move from the env kernels' device outputs and draws the exploration noise on
+    the device; the games it files -- actions, rewards, players, child visits, root values, observations -- are the
+    ones step() files with the host in every move."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("tictactoe").MuZeroConfig()
+    config.network, config.encoding_size = "fullyconnected", 8
+    config.fc_representation_layers, config.fc_dynamics_layers = [], [16]
+    config.fc_reward_layers = config.fc_value_layers = config.fc_policy_layers = [16]
+    config.num_simulations = 20
+    config.temperature_threshold = None
+    torch.manual_seed(0)
+    weights = models_mod.MuZeroNetwork(config).get_weights()
+    E, total = 96, 35
+    finished = {}
+    for kind in ("step", "batch"):
+        games_done = {}
+        actor = sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E)
+
+        def on_games(batch):
+            for i, e in enumerate(batch.env_index):
+                games_done.setdefault(int(e), []).append(batch.history(i))
+        if kind == "step":
+            for _ in range(total):
+                actor.step(1.0, None, on_games=on_games)
+        else:
+            played = np.zeros(E, np.int64)
+            for n in (7, 7, 7):
+                played += actor.play_moves(n, 1.0, on_games=on_games)
+            actor.step(1.0, None, on_games=on_games)        # the two forms mix: same rows, same RNG streams
+            played += 1
+            played += actor.play_moves(13, 1.0, on_games=on_games)
+            assert (played == total).all()
+        assert actor.moves_played == E * total
+        actor.close()
+        finished[kind] = games_done
+    compared = 0
+    for e in range(E):
+        a, b = finished["step"].get(e, []), finished["batch"].get(e, [])
+        assert len(a) == len(b) >= 3, e
+        for ga, gb in zip(a, b):
+            assert ga.action_history == gb.action_history and ga.reward_history == gb.reward_history, e
+            assert ga.to_play_history == gb.to_play_history, e
+            assert np.array_equal(np.array(ga.child_visits), np.array(gb.child_visits))
+            assert ga.root_values == gb.root_values
+            assert all(np.array_equal(x, y) for x, y in zip(ga.observation_history, gb.observation_history))
+            compared += 1
+    assert compared >= 3 * E
+
+
 def test_pipelined_actor_passes_with_weight_changes_equal_single_actor(dev, pkg):
     """ManyEnvLoop passes (moves_per_pass = 3) with a weight change between them: the pipelined actor leaves no search
     queued across the change, so both actors search every move with the same weights and finish the same games."""
