@@ -47,6 +47,8 @@ typedef struct mzhist_moves {
     const float *obs_next;        /* [M][E][obs] observation the next search sees (reset where done) */
     const int32_t *to_play_after; /* [M][E] or NULL (single player) */
     const int32_t *to_play_next;  /* [M][E] or NULL */
+    int64_t legal_stride;         /* bytes from one move's legal sets to the next move's; 0 = the batch has one set */
+    int64_t num_legal_stride;     /* (board games: mzmcts_moves_inputs hands out [M][E][A] / [M][E]) */
 } mzhist_moves;
 
 /* File the batch; *n_finished = games that ended in it. */

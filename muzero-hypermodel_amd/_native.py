@@ -254,7 +254,8 @@ class MzHistMoves(ctypes.Structure):
                 ("actions", c_void), ("actions_stride", ctypes.c_int64), ("visits", c_void),
                 ("visits_stride", ctypes.c_int64), ("root_value_sum", c_void), ("root_value_sum_stride", ctypes.c_int64),
                 ("legal", c_void), ("num_legal", c_void), ("rewards", c_void), ("done", c_void), ("obs_after", c_void),
-                ("obs_next", c_void), ("to_play_after", c_void), ("to_play_next", c_void)]
+                ("obs_next", c_void), ("to_play_after", c_void), ("to_play_next", c_void),
+                ("legal_stride", ctypes.c_int64), ("num_legal_stride", ctypes.c_int64)]
 
 
 class HostRng:

@@ -150,14 +150,14 @@ int mzhist_file(mzhist* h, const mzhist_moves* mv, int32_t* n_finished) {
             int32_t* row_tp = h->to_play.data() + static_cast<size_t>(e) * L1;
             double* row_cv = h->child_visits.data() + static_cast<size_t>(e) * L * A;
             double* row_rv = h->root_values.data() + static_cast<size_t>(e) * L;
-            const int32_t* legal = mv->legal + static_cast<size_t>(e) * A;
-            const int n_legal = mv->num_legal[e];
             int len = h->length[e];
             int out_slot = h->fin_offset[e];
             const int k = std::min(mv->moves_done[e], M);
             for (int m = 0; m < k; ++m) {
                 const size_t me = static_cast<size_t>(m) * E + e;
                 const int32_t* visits = reinterpret_cast<const int32_t*>(at(mv->visits, mv->visits_stride, m)) + static_cast<size_t>(e) * A;
+                const int32_t* legal = reinterpret_cast<const int32_t*>(at(mv->legal, mv->legal_stride, m)) + static_cast<size_t>(e) * A;
+                const int n_legal = reinterpret_cast<const int32_t*>(at(mv->num_legal, mv->num_legal_stride, m))[e];
                 double* cv = row_cv + static_cast<size_t>(len) * A;
                 for (int a = 0; a < A; ++a) cv[a] = 0.0;
                 for (int i = 0; i < n_legal; ++i) cv[legal[i]] = static_cast<double>(visits[i]) / S;

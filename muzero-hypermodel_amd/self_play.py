@@ -760,7 +760,8 @@ class HistoryFiler:
 
     def file(self, out, legal, num_legal, num_simulations, rewards, done, obs_after, obs_next, to_play_after=None,
              to_play_next=None):
-        """out: engine.moves_collect() result (copies or ring views); rewards f32 [M,E], done u8 [M,E],
+        """out: engine.moves_collect() result (copies or ring views); legal [E,A] / num_legal [E] for the whole batch or
+        [M,E,A] / [M,E] per move (engine.moves_inputs); rewards f32 [M,E], done u8 [M,E],
         obs_after / obs_next f32 [M,E,...] host arrays; to_play_after / to_play_next [M,E] for two-player games.
         Returns PackedGames of the games that ended, or None."""
         ct = self._ct
@@ -777,6 +778,9 @@ class HistoryFiler:
             setattr(mv, name, a.ctypes.data)
             setattr(mv, name + "_stride", int(a.strides[0]) if M else 0)
         mv.legal, mv.num_legal = keep[1].ctypes.data, keep[2].ctypes.data
+        per_move = keep[1].ndim == 3                      # legal [M, E, A], num_legal [M, E]: one set per move
+        mv.legal_stride = int(keep[1].strides[0]) if per_move else 0
+        mv.num_legal_stride = int(keep[2].strides[0]) if per_move else 0
         mv.rewards, mv.done, mv.obs_after, mv.obs_next = (k.ctypes.data for k in keep[3:7])
         mv.to_play_after = mv.to_play_next = None
         if to_play_after is not None:
@@ -989,7 +993,7 @@ class DeviceSelfPlay(ManyEnvLoop):
         host = {k: pinned[k][:n_moves].numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         eng.moves_submit_next()
         self._batch_ready = params
-        self._unfiled = (out, host, cur["legal"], cur["num_legal"], n_moves)
+        self._unfiled = (out, host, cur["legal"], cur["num_legal"], n_moves, None, None)
         self._cur = dict(cur, obs_dev=obs_in, obs=host["obs_next"][n_moves - 1])
         self.moves_played += int(out["moves_done"].sum())
         return out["moves_done"].copy()
@@ -1002,7 +1006,6 @@ class DeviceSelfPlay(ManyEnvLoop):
         E, eng, envs = self.E, self.engine, self.envs
         if eng._fc_model is None:
             raise NotImplementedError("play_moves runs the fused whole-move search: a fully-connected network")
-        self.flush(on_game, on_games)
         self._drop_batch()
         cur = self._cur
         eng.moves_prepare_device(n_moves, envs.legal, envs.num_legal, envs.to_play, temperature, True)
@@ -1012,29 +1015,20 @@ class DeviceSelfPlay(ManyEnvLoop):
             eng.moves_enqueue(obs_in.reshape(E, -1).contiguous())
             obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
                                   ring["obs_next"][m])
+        self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         out = eng.moves_collect()
         inputs = eng.moves_inputs(n_moves)
-        host = {k: ring[k][:n_moves].cpu().numpy() for k in ("reward", "done", "obs_after", "obs_next")}
-        last_to_play = envs.to_play.cpu().numpy()
+        pinned = ring["pinned"][ring["flip"]]
+        ring["flip"] ^= 1
+        for k in ("reward", "done", "obs_after", "obs_next"):
+            pinned[k][:n_moves].copy_(ring[k][:n_moves], non_blocking=True)
+        last_to_play = envs.to_play.cpu().numpy()        # (waits for the copies queued before it)
+        host = {k: pinned[k][:n_moves].numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         two_players = len(self.config.players) > 1
-        filer = self._history_filer()
-        for m in range(n_moves):
-            played = (out["moves_done"] > m).astype(numpy.int32)
-            to_play_after = (1 - inputs["to_play"][m]) if two_players else numpy.zeros(E, numpy.int32)
-            to_play_next = inputs["to_play"][m + 1] if m + 1 < n_moves else last_to_play
-            one = {"actions": out["actions"][m][None], "visits": out["visits"][m][None],
-                   "root_value_sum": out["root_value_sum"][m][None], "moves_done": played}
-            batch = filer.file(one, inputs["legal"][m], inputs["num_legal"][m], self.config.num_simulations,
-                               host["reward"][m][None], host["done"][m][None], host["obs_after"][m][None],
-                               host["obs_next"][m][None], to_play_after=to_play_after[None], to_play_next=to_play_next[None])
-            if batch is not None:
-                self.games_finished += len(batch)
-                if on_games is not None:
-                    on_games(batch)
-                if on_game is not None:
-                    for i, e in enumerate(batch.env_index):
-                        on_game(int(e), batch.history(i))
-        self._len[:] = filer.lengths()
+        to_play = inputs["to_play"]
+        to_play_after = (1 - to_play) if two_players else numpy.zeros_like(to_play)
+        to_play_next = numpy.concatenate([to_play[1:], last_to_play[None]], axis=0)
+        self._unfiled = (out, host, inputs["legal"], inputs["num_legal"], n_moves, to_play_after, to_play_next)
         nxt = self._observe_host()                       # (the envs' current state: what the next step / batch searches)
         self._cur = nxt
         self.moves_played += int(out["moves_done"].sum())
@@ -1060,11 +1054,11 @@ class DeviceSelfPlay(ManyEnvLoop):
         (HistoryFiler, include/mzhist.h): one pass over the batch on the library's worker pool."""
         if getattr(self, "_unfiled", None) is None:
             return
-        out, host, legal, num_legal, n_moves = self._unfiled
+        out, host, legal, num_legal, n_moves, to_play_after, to_play_next = self._unfiled
         self._unfiled = None
         filer = self._history_filer()
         batch = filer.file(out, legal, num_legal, self.config.num_simulations, host["reward"], host["done"],
-                           host["obs_after"], host["obs_next"])
+                           host["obs_after"], host["obs_next"], to_play_after=to_play_after, to_play_next=to_play_next)
         self._len[:] = filer.lengths()
         if batch is not None:
             self.games_finished += len(batch)

@@ -249,6 +249,7 @@ def test_board_game_self_play_in_move_batches_equals_move_by_move(dev, pkg):
             actor.step(1.0, None, on_games=on_games)        # the two forms mix: same rows, same RNG streams
             played += 1
             played += actor.play_moves(13, 1.0, on_games=on_games)
+            actor.flush(on_games=on_games)
             assert (played == total).all()
         assert actor.moves_played == E * total
         actor.close()

@@ -28,9 +28,16 @@ def main():
     ap.add_argument("--weights", default="random", choices=["random", "checkpoint"],
                     help="checkpoint: the reference's trained CartPole weights (tests/golden/cartpole_weights.npz): long "
                          "games and the benchmark's tree depths; random: seed-0 initialisation, games of ~15 moves")
+    ap.add_argument("--fc", type=int, default=0, help="N > 0: play the game with a fully-connected network (the reference's "
+                    "network = 'fullyconnected'), encoding and layers of N units -- board games through the fused whole-move search")
     args = ap.parse_args()
     mod = importlib.import_module(f"muzero-hypermodel_amd.games.{args.game}")
     config = mod.MuZeroConfig()
+    if args.fc:
+        config.network, config.encoding_size = "fullyconnected", args.fc
+        config.fc_representation_layers, config.fc_dynamics_layers = [], [args.fc]
+        config.fc_reward_layers = config.fc_value_layers = config.fc_policy_layers = [args.fc]
+        config.temperature_threshold = None
     torch.manual_seed(0)
     weights = models.MuZeroNetwork(config).get_weights()
     if args.weights == "checkpoint":
