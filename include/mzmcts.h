@@ -409,7 +409,8 @@ int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t chan
  * mzmcts_board_conv_pack_split (mzmcts_board_conv_split_halfs(cin_conv, cout) 16-bit words; cin_conv = cin - 1 when
  * const_plane).  const_plane != 0: the LAST input plane of x is one constant per sample (the dynamics input's action
  * plane, models.py:553-568); it is not convolved, its contribution comes from `const_table` (dev f32[cout, height *
- * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN). */
+ * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN).
+ * `scale` / `shift` of every layer must be 16-byte aligned (read four channels at a time). */
 int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout);
 int mzmcts_board_conv_pack_split(const float *weight, void *packed, float *const_table, int32_t cin, int32_t cout,
                                  int32_t const_plane, int32_t height, int32_t width, void *stream);

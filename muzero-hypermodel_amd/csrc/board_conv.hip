@@ -595,6 +595,7 @@ static int launch_board_tower(const float* x, int batch, int cin0, const TowerAr
 // a * sum over the taps inside the board of w[n][C][tap] comes from a table made at pack time (fp32).
 // -------------------------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr float kActScale = 8.f, kWtScale = 64.f;
 constexpr int kSplitGroup = 32;   // input channels per MFMA (K of v_mfma_f32_16x16x32_f16)
 
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     const int wave = tid >> 6;
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
+    MZ_TSTAMP_DECL
     const int buf1_at = SB * PP * 2 * cph0;             // (offsets into hl, so that every access stays an LDS access)
     float* aconst = reinterpret_cast<float*>(hl + SB * PP * 2 * (cph0 + cph1));   // [SB] the constant plane's value
 
@@ -697,6 +699,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         for (int i = tid; i < bytes / 16; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    MZ_TSTAMP(0);
     {
         const int cin_load = cin0 - const_plane;
         const float* src = x + static_cast<size_t>(b0) * cin0 * P;
@@ -754,6 +757,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         }
     }
     __syncthreads();
+    MZ_TSTAMP(1);
 
     const int col_pair = wave & 1;                      // output channels col_pair * 32 .. + 31
     const int row_group = wave >> 1;
@@ -768,17 +772,17 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         pos_a[t] = (m / P) * PP + plane_pos(m % P);
     }
 
-    // plane position of the D rows this lane stores (row 4 kk + r of its tiles), -1 = not a row of a present sample
-    int pos_d[MTW][4];
+    // The products are issued as W x X^T (weights as the MFMA's first operand): a lane's four D values are FOUR
+    // CONSECUTIVE OUTPUT CHANNELS (4 kk + r of its column tile) of ONE position (i_row of its row tile), so the epilogue
+    // reads the skip connection and writes the result with 8-byte LDS accesses.
+    // plane position of the D column this lane stores, -1 = not a position of a present sample
+    int pos_d[MTW];
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
         const int tile = row_group + t * RG;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = tile * 16 + 4 * kk + r;
-            const bool ok = tile < MT && m < ROWS && m / P < n_samples;
-            pos_d[t][r] = ok ? (m / P) * PP + plane_pos(m % P) : -1;
-        }
+        const int m = tile * 16 + i_row;
+        const bool ok = tile < MT && m < ROWS && m / P < n_samples;
+        pos_d[t] = ok ? (m / P) * PP + plane_pos(m % P) : -1;
     }
     // the first two weight groups of a layer are fetched before the previous layer's epilogue (L2 / HBM latency)
     h8 bq[2][2];
@@ -838,26 +842,26 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
 #pragma unroll
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) hi[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], b[c][0], hi[t][c], 0, 0, 0);
+                for (int c = 0; c < 2; ++c) hi[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[c][0], a[t][0], hi[t][c], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], b[c][1], lo[t][c], 0, 0, 0);
+                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[c][1], a[t][0], lo[t][c], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], b[c][0], lo[t][c], 0, 0, 0);
+                for (int c = 0; c < 2; ++c) lo[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[c][0], a[t][1], lo[t][c], 0, 0, 0);
         };
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q) w_even[c][q] = bq[c][q];
         fetch_b(w_odd, 1);
-        float sc2[2], sh2[2];                            // folded batch norm of this lane's two columns (in flight early)
+        float4 sc4[2], sh4[2];                           // folded batch norm of this lane's 2 x 4 channels (in flight early)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            sc2[c] = L.scale[col_pair * 32 + c * 16 + i_row];
-            sh2[c] = L.shift[col_pair * 32 + c * 16 + i_row];
+            sc4[c] = *reinterpret_cast<const float4*>(L.scale + col_pair * 32 + c * 16 + 4 * kk);
+            sh4[c] = *reinterpret_cast<const float4*>(L.shift + col_pair * 32 + c * 16 + 4 * kk);
         }
         fetch_a(a_even);
         fetch_a(a_odd);
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             fetch_a(a_odd);
             fetch_b(w_odd, min(it + 3, iterations + 1));
         }
+        MZ_TSTAMP(2);
 
         if (l + 1 < args.n_layers) {                     // next layer's first weights: in flight under this epilogue
 #pragma unroll
@@ -878,30 +883,45 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                     bq[c][q] = wload_of(args.layer[l + 1], 0, c, q);
                 }
         }
-        // ---- layer epilogue: D[row = 4 kk + r][col = lane & 15] of column tiles 2 col_pair, 2 col_pair + 1 --------------
+        // ---- layer epilogue: D[channel = 4 kk + r][position = lane & 15] of column tiles 2 col_pair, 2 col_pair + 1 ----
         constexpr float kDescale = 1.0f / (kActScale * kWtScale);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int n = col_pair * 32 + c * 16 + i_row;
+            const int n0 = col_pair * 32 + c * 16 + 4 * kk;
+            const float scl[4] = {sc4[c].x, sc4[c].y, sc4[c].z, sc4[c].w};
+            const float sft[4] = {sh4[c].x, sh4[c].y, sh4[c].z, sh4[c].w};
 #pragma unroll
             for (int t = 0; t < MTW; ++t) {
+                const int pos = pos_d[t];
+                if (pos < 0) continue;
+                h4* cell = reinterpret_cast<h4*>(hl + dst + pos * 2 * CPO + n0);      // halves 0; halves 1 are CPO further
+                h4 s0 = h4{0, 0, 0, 0}, s1 = s0;
+                if (L.skip) {
+                    s0 = cell[0];
+                    s1 = *reinterpret_cast<const h4*>(hl + dst + pos * 2 * CPO + CPO + n0);
+                }
+                h4 o0, o1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int pos = pos_d[t][r];
-                    if (pos < 0) continue;
                     float conv = (hi[t][c][r] + lo[t][c][r]) * kDescale;
                     if (L.const_table) {                 // (layer 0 only) position inside the board from the plane position
                         const int pp = pos % PP;
-                        conv = conv + aconst[pos / PP] * L.const_table[n * P + (pp / PW - 1) * W + pp % PW - 1];
+                        conv = conv + aconst[pos / PP] * L.const_table[(n0 + r) * P + (pp / PW - 1) * W + pp % PW - 1];
                     }
-                    float v = conv * sc2[c] + sh2[c];
-                    if (L.skip) v = v + load_val(dst, CPO, pos, n);
+                    float v = conv * scl[r] + sft[r];
+                    if (L.skip) v = v + (static_cast<float>(s0[r]) + static_cast<float>(s1[r])) * (1.0f / kActScale);
                     if (L.relu) v = v < 0.f ? 0.f : v;
-                    store_val(dst, CPO, pos, n, v);
+                    const float vs = v * kActScale;
+                    o0[r] = static_cast<_Float16>(vs);
+                    o1[r] = static_cast<_Float16>(vs - static_cast<float>(o0[r]));
                 }
+                cell[0] = o0;
+                *reinterpret_cast<h4*>(hl + dst + pos * 2 * CPO + CPO + n0) = o1;
             }
         }
+        MZ_TSTAMP(3);
         __syncthreads();
+        MZ_TSTAMP(4);
 
         if (L.export_raw || L.export_unit) {
             const int out_count = n_samples * COUT * P;
@@ -938,8 +958,10 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                 }
             }
             __syncthreads();
+            MZ_TSTAMP(5);
         }
     }
+    MZ_TSTAMP_FLUSH;
 }
 
 template <int H, int W, int SB>
@@ -1112,6 +1134,8 @@ static int board_tower_split_impl(const float* x, const mz::TowerGather& gather,
         if (!d.packed || !d.scale || !d.shift || d.cin != (l == 0 ? cin0 : channels) ||
             (l == 0 && const_plane && !d.const_table))
             return MZMCTS_ERR_INVALID;
+        if ((reinterpret_cast<uintptr_t>(d.scale) | reinterpret_cast<uintptr_t>(d.shift)) & 15u)
+            return MZMCTS_ERR_INVALID;                   // (read four channels at a time)
         args.layer[l] = mz::SplitLayer{static_cast<const _Float16*>(d.packed), d.scale, d.shift,
                                        (l == 0 && const_plane) ? d.const_table : nullptr, d.export_raw, d.export_unit,
                                        cin_conv, d.relu, d.skip, 0};
