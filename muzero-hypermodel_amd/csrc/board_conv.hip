@@ -804,6 +804,8 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         const int CPI = (l & 1) ? cph1 : cph0, CPO = (l & 1) ? cph0 : cph1;
         const int ng = split_groups(L.cin);
         const int iterations = 9 * ng;
+        const int skip = L.skip, relu = L.relu;          // (read now: in registers long before the epilogue asks)
+        const float* ctab = L.const_table;
 
         f32x4 hi[MTW][2], lo[MTW][2];
 #pragma unroll
@@ -884,39 +886,41 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                 }
         }
         // ---- layer epilogue: D[channel = 4 kk + r][position = lane & 15] of column tiles 2 col_pair, 2 col_pair + 1 ----
+        // (four channels at a time as vectors: two-wide fp32 instructions where the chip has them; plain IEEE operations)
         constexpr float kDescale = 1.0f / (kActScale * kWtScale);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int n0 = col_pair * 32 + c * 16 + 4 * kk;
-            const float scl[4] = {sc4[c].x, sc4[c].y, sc4[c].z, sc4[c].w};
-            const float sft[4] = {sh4[c].x, sh4[c].y, sh4[c].z, sh4[c].w};
+            const f32x4 scl = {sc4[c].x, sc4[c].y, sc4[c].z, sc4[c].w};
+            const f32x4 sft = {sh4[c].x, sh4[c].y, sh4[c].z, sh4[c].w};
 #pragma unroll
             for (int t = 0; t < MTW; ++t) {
                 const int pos = pos_d[t];
                 if (pos < 0) continue;
-                h4* cell = reinterpret_cast<h4*>(hl + dst + pos * 2 * CPO + n0);      // halves 0; halves 1 are CPO further
-                h4 s0 = h4{0, 0, 0, 0}, s1 = s0;
-                if (L.skip) {
-                    s0 = cell[0];
-                    s1 = *reinterpret_cast<const h4*>(hl + dst + pos * 2 * CPO + CPO + n0);
+                // (indexed in units of four halves: CPO and n0 are multiples of 4, and the compiler may use 8-byte accesses)
+                h4* cell0 = reinterpret_cast<h4*>(hl) + ((dst + pos * 2 * CPO + n0) >> 2);          // halves 0
+                h4* cell1 = reinterpret_cast<h4*>(hl) + ((dst + pos * 2 * CPO + CPO + n0) >> 2);    // halves 1
+                f32x4 conv = (hi[t][c] + lo[t][c]) * kDescale;
+                if (ctab) {                              // (layer 0 only) position inside the board from the plane position
+                    const int pp = pos % PP;
+                    const float a = aconst[pos / PP];
+                    const float* tab = ctab + n0 * P + (pp / PW - 1) * W + pp % PW - 1;
+                    conv = conv + a * f32x4{tab[0], tab[P], tab[2 * P], tab[3 * P]};
                 }
-                h4 o0, o1;
+                f32x4 v = conv * scl + sft;
+                if (skip) {
+                    const h4 s0 = *cell0, s1 = *cell1;
+                    v = v + (__builtin_convertvector(s0, f32x4) + __builtin_convertvector(s1, f32x4)) * (1.0f / kActScale);
+                }
+                if (relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float conv = (hi[t][c][r] + lo[t][c][r]) * kDescale;
-                    if (L.const_table) {                 // (layer 0 only) position inside the board from the plane position
-                        const int pp = pos % PP;
-                        conv = conv + aconst[pos / PP] * L.const_table[(n0 + r) * P + (pp / PW - 1) * W + pp % PW - 1];
-                    }
-                    float v = conv * scl[r] + sft[r];
-                    if (L.skip) v = v + (static_cast<float>(s0[r]) + static_cast<float>(s1[r])) * (1.0f / kActScale);
-                    if (L.relu) v = v < 0.f ? 0.f : v;
-                    const float vs = v * kActScale;
-                    o0[r] = static_cast<_Float16>(vs);
-                    o1[r] = static_cast<_Float16>(vs - static_cast<float>(o0[r]));
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
                 }
-                cell[0] = o0;
-                *reinterpret_cast<h4*>(hl + dst + pos * 2 * CPO + CPO + n0) = o1;
+                const f32x4 vs = v * kActScale;
+                const h4 o0 = __builtin_convertvector(vs, h4);
+                const h4 o1 = __builtin_convertvector(vs - __builtin_convertvector(o0, f32x4), h4);
+                *cell0 = o0;
+                *cell1 = o1;
             }
         }
         MZ_TSTAMP(3);
