@@ -678,6 +678,12 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     MZ_TSTAMP_DECL
     const int buf1_at = SB * PP * 2 * cph0;             // (offsets into hl, so that every access stays an LDS access)
     float* aconst = reinterpret_cast<float*>(hl + SB * PP * 2 * (cph0 + cph1));   // [SB] the constant plane's value
+    const float** in_row = reinterpret_cast<const float**>(aconst + SB);            // [SB] where sample q's input planes start
+    // A thread of the plane-wise passes (input fill, exports) keeps ONE board position and walks over the (sample, channel)
+    // planes, TPP planes per pass: consecutive threads touch consecutive addresses of global memory, and the position's
+    // arithmetic is done once.
+    constexpr int TPP = THREADS / P;
+    constexpr int WALKERS = TPP * P;
 
     auto plane_pos = [&](int p) { return (p / W + 1) * PW + (p % W) + 1; };
     auto store_val = [&](int b, int cph, int pos, int n, float v) {       // b: the buffer's offset in hl
@@ -693,56 +699,46 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     };
 
     // ---- zero both buffers, then the tower's input (without the constant plane) into buffer 0 ---------------------
+    const int cin_load = cin0 - const_plane;
     {
         const int bytes = (SB * PP * 2 * (cph0 + cph1)) * 2;          // a multiple of 16
         float4* z = reinterpret_cast<float4*>(hl);
         for (int i = tid; i < bytes / 16; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < SB) {
+            // (gathered input: rows of the hidden-state pool, the constant plane is action / action_space)
+            const long long b = b0 + tid;
+            const float* row = nullptr;
+            float plane_value = 0.f;
+            if (tid < n_samples) {
+                row = gather.pool ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden
+                                  : x + static_cast<size_t>(b) * cin0 * P;
+                if (const_plane)
+                    plane_value = gather.pool ? static_cast<float>(gather.action[b]) / gather.action_space
+                                              : row[static_cast<size_t>(cin_load) * P];
+            }
+            in_row[tid] = row;
+            aconst[tid] = plane_value;
+        }
     }
     __syncthreads();
     MZ_TSTAMP(0);
-    {
-        const int cin_load = cin0 - const_plane;
-        const float* src = x + static_cast<size_t>(b0) * cin0 * P;
-        // (gathered input: rows of the hidden-state pool, the constant plane is action / action_space)
-        // (the SB rows' addresses once per thread, up front: looked up per element, every load would wait for its
-        // parent-index load first)
-        const float* rows[SB];
-#pragma unroll
-        for (int q = 0; q < SB; ++q) {
-            const long long b = b0 + q;
-            rows[q] = (gather.pool && q < n_samples)
-                          ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden
-                          : nullptr;
-        }
-        auto pool_row = [&](int sidx) {
-            const float* r = rows[0];
-#pragma unroll
-            for (int q = 1; q < SB; ++q) r = (sidx == q) ? rows[q] : r;
-            return r;
-        };
-        if (tid < SB) {
-            float plane_value = 0.f;
-            if (const_plane && tid < n_samples)
-                plane_value = gather.pool ? static_cast<float>(gather.action[b0 + tid]) / gather.action_space
-                                          : src[(static_cast<size_t>(tid) * cin0 + cin_load) * P];
-            aconst[tid] = plane_value;
-        }
-        const int count = n_samples * cin_load * P;       // elements to place; sample s, channel ci, position p
-        for (int i0 = tid; i0 < count; i0 += 4 * THREADS) {
+    if (tid < WALKERS) {
+        const int p = tid % P;
+        const int at_p = plane_pos(p) * 2 * cph0;
+        const int planes = n_samples * cin_load;         // plane sc = sample * cin_load + channel
+        for (int sc0 = tid / P; sc0 < planes; sc0 += 4 * TPP) {
             float v[4];
             int at[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * THREADS;
+                const int sc = sc0 + k * TPP;
                 at[k] = -1;
                 v[k] = 0.f;
-                if (i < count) {
-                    const int p = i % P;
-                    const int sc = i / P;                 // s * cin_load + ci
+                if (sc < planes) {
                     const int sidx = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin_load_magic));
                     const int ci = sc - sidx * cin_load;
-                    v[k] = gather.pool ? pool_row(sidx)[ci * P + p] : src[(static_cast<size_t>(sidx) * cin0 + ci) * P + p];
-                    at[k] = (sidx * PP + plane_pos(p)) * 2 * cph0 + ci;
+                    v[k] = in_row[sidx][ci * P + p];
+                    at[k] = sidx * PP * 2 * cph0 + at_p + ci;
                 }
             }
 #pragma unroll
@@ -928,15 +924,16 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
         MZ_TSTAMP(4);
 
         if (L.export_raw || L.export_unit) {
-            const int out_count = n_samples * COUT * P;
+            const int planes = n_samples * COUT;         // plane sn = sample * COUT + channel
             const size_t g0 = static_cast<size_t>(b0) * COUT * P;
-            if (L.export_raw) {
-                for (int i = tid; i < out_count; i += THREADS) {
-                    const int p = i % P;
-                    const int sn = i / P;
-                    L.export_raw[g0 + i] = load_val(dst, CPO, (sn / COUT) * PP + plane_pos(p), sn % COUT);
-                }
-            }
+            const int walker_p = tid % P;
+            const int walker_at = plane_pos(walker_p);
+            auto export_planes = [&](float* out) {
+                if (tid < WALKERS)
+                    for (int sn = tid / P; sn < planes; sn += TPP)
+                        out[g0 + sn * P + walker_p] = load_val(dst, CPO, (sn / COUT) * PP + walker_at, sn % COUT);
+            };
+            if (L.export_raw) export_planes(L.export_raw);
             if (L.export_unit) {
                 __syncthreads();
                 for (int q = tid; q < n_samples * COUT; q += THREADS) {   // per plane: models.py:525-549
@@ -955,11 +952,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                     }
                 }
                 __syncthreads();
-                for (int i = tid; i < out_count; i += THREADS) {
-                    const int p = i % P;
-                    const int sn = i / P;
-                    L.export_unit[g0 + i] = load_val(dst, CPO, (sn / COUT) * PP + plane_pos(p), sn % COUT);
-                }
+                export_planes(L.export_unit);
             }
             __syncthreads();
             MZ_TSTAMP(5);
@@ -977,7 +970,7 @@ static int launch_board_tower_split(const float* x, int batch, int cin0, int con
         int& cp = (l & 1) ? cph1 : cph0;
         cp = std::max(cp, split_groups(args.layer[l].cin) * kSplitGroup + 8);
     }
-    const size_t lds = sizeof(_Float16) * static_cast<size_t>(SB) * PP * 2 * (cph0 + cph1) + sizeof(float) * SB;
+    const size_t lds = sizeof(_Float16) * static_cast<size_t>(SB) * PP * 2 * (cph0 + cph1) + (sizeof(float) + sizeof(float*)) * SB;
     if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
     auto kernel = board_tower_split_kernel<H, W, SB>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
