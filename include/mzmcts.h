@@ -396,7 +396,7 @@ int mzmcts_board_conv3x3(const float *x, const float *packed, const float *scale
  * when two activation buffers of the workgroup do not fit in LDS (the caller keeps the per-layer path). */
 typedef struct mzmcts_tower_layer {
     const void *packed;        /* mzmcts_board_conv_pack (fp32 tower) or mzmcts_board_conv_pack_split (split tower) */
-    const float *scale, *shift;
+    const float *scale, *shift; /* dev f32[channels] each, 16-byte aligned (the towers read four channels at a time) */
     const float *const_table;  /* split tower, layer 0 with a constant last input plane: its table; else NULL */
     float *export_raw, *export_unit;
     int32_t cin, relu, skip, reserved;
@@ -409,8 +409,7 @@ int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t chan
  * mzmcts_board_conv_pack_split (mzmcts_board_conv_split_halfs(cin_conv, cout) 16-bit words; cin_conv = cin - 1 when
  * const_plane).  const_plane != 0: the LAST input plane of x is one constant per sample (the dynamics input's action
  * plane, models.py:553-568); it is not convolved, its contribution comes from `const_table` (dev f32[cout, height *
- * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN).
- * `scale` / `shift` of every layer must be 16-byte aligned (read four channels at a time). */
+ * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN). */
 int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout);
 int mzmcts_board_conv_pack_split(const float *weight, void *packed, float *const_table, int32_t cin, int32_t cout,
                                  int32_t const_plane, int32_t height, int32_t width, void *stream);

@@ -404,15 +404,20 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int i_row = lane & 15;
     const int kk = lane >> 4;
     const int n_col = col_tile * 16 + i_row;
-    // plane position (word offset / channel stride) of this lane's A rows and of the D rows it stores
-    int pos_a[MTW];
+    // plane position (word offset / channel stride) of this lane's A rows, and of the D column it stores (-1 = not a
+    // position of a present sample).  The products are issued as W x X^T (weights as the MFMA's first operand; the same
+    // k-ordered sums): a lane's four D values are FOUR CONSECUTIVE OUTPUT CHANNELS (4 kk + r of its column tile) of
+    // position i_row of its row tile, so the epilogue is one 16-byte LDS read and write per tile with no index arithmetic.
+    int pos_a[MTW], pos_d[MTW];
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
         const int tile = row_group + t * RG;
         int m = tile * 16 + i_row;
+        const bool present = tile < MT && m < ROWS && m / P < n_samples;
         if (tile >= MT || m >= ROWS) m = 0;
         const int sidx = m / P, p = m % P;
         pos_a[t] = sidx * PP + (p / W + 1) * PW + (p % W) + 1;
+        pos_d[t] = present ? pos_a[t] : -1;
     }
 
     for (int l = 0; l < args.n_layers; ++l) {
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                    for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+                    for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g], a[t][g], acc[t], 0, 0, 0);
                 }
             } else {
 #pragma unroll
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                     if (g < steps) {
 #pragma unroll
                         for (int t = 0; t < MTW; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g], b[g], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[g], a[t][g], acc[t], 0, 0, 0);
                     }
                 }
             }
@@ -488,22 +493,23 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         }
 
         MZ_TSTAMP(2);
-        // ---- layer epilogue into the destination planes: D[row = 4 kk + r][col = lane & 15] ----------------------------
-        const float sc = L.scale[n_col], sh = L.shift[n_col];
+        // ---- layer epilogue into the destination planes: D[channel = 4 kk + r][position = lane & 15] ------------------
+        {
+            const float4 s4 = *reinterpret_cast<const float4*>(L.scale + col_tile * 16 + 4 * kk);
+            const float4 h4v = *reinterpret_cast<const float4*>(L.shift + col_tile * 16 + 4 * kk);
+            const f32x4 sc = {s4.x, s4.y, s4.z, s4.w}, sh = {h4v.x, h4v.y, h4v.z, h4v.w};
+            const int skip = L.skip, relu = L.relu;
 #pragma unroll
-        for (int t = 0; t < MTW; ++t) {
-            const int tile = row_group + t * RG;
-            if (tile >= MT) continue;
+            for (int t = 0; t < MTW; ++t) {
+                const int pos = pos_d[t];
+                if (pos < 0) continue;                  // (missing samples stay zero)
+                f32x4* cell = reinterpret_cast<f32x4*>(lds) + ((dst + pos * CPO + col_tile * 16 + 4 * kk) >> 2);   // (16-byte aligned)
+                f32x4 v = acc[t] * sc + sh;
+                if (skip) v = v + *cell;
+                if (relu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = tile * 16 + 4 * kk + r;
-                if (m >= ROWS) continue;
-                const int sidx = m / P, p = m % P;
-                if (sidx >= n_samples) continue;        // (missing samples stay zero)
-                float* cell = &lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n_col];
-                float v = acc[t][r] * sc + sh;
-                if (L.skip) v = v + *cell;
-                if (L.relu) v = v < 0.f ? 0.f : v;
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+                }
                 *cell = v;
             }
         }
@@ -512,16 +518,18 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         MZ_TSTAMP(4);
 
         if (L.export_raw || L.export_unit) {
-            const int out_count = n_samples * COUT * P;
+            // (a thread keeps one board position and walks over the (sample, channel) planes, TPP planes per pass:
+            // consecutive threads write consecutive addresses, the position's arithmetic is done once)
+            constexpr int TPP = THREADS / P;
             const size_t g0 = static_cast<size_t>(b0) * COUT * P;
-            if (L.export_raw) {
-                for (int i = tid; i < out_count; i += THREADS) {
-                    const int p = i % P;
-                    const int sn = i / P;
-                    const int n = sn % COUT, sidx = sn / COUT;
-                    L.export_raw[g0 + i] = lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
-                }
-            }
+            const int walker_p = tid % P;
+            const int walker_at = (walker_p / W + 1) * PW + (walker_p % W) + 1;
+            auto export_planes = [&](float* out) {
+                if (tid < TPP * P)
+                    for (int sn = tid / P; sn < n_samples * COUT; sn += TPP)
+                        out[g0 + sn * P + walker_p] = lds[dst + ((sn / COUT) * PP + walker_at) * CPO + sn % COUT];
+            };
+            if (L.export_raw) export_planes(L.export_raw);
             if (L.export_unit) {
                 // per (sample, channel) plane: (x - min) / span, span = max - min (+ 1e-5 below 1e-5) -- models.py:525-549,
                 // the operations of unit_rescale_kernel, so the same bits
@@ -543,12 +551,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
                     }
                 }
                 __syncthreads();
-                for (int i = tid; i < out_count; i += THREADS) {
-                    const int p = i % P;
-                    const int sn = i / P;
-                    const int n = sn % COUT, sidx = sn / COUT;
-                    L.export_unit[g0 + i] = lds[dst + (sidx * PP + (p / W + 1) * PW + (p % W) + 1) * CPO + n];
-                }
+                export_planes(L.export_unit);
             }
             __syncthreads();
             MZ_TSTAMP(5);
@@ -1063,6 +1066,8 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     for (int l = 0; l < n_layers; ++l) {
         const mzmcts_tower_layer& d = layers[l];
         if (!d.packed || !d.scale || !d.shift || d.cin != (l == 0 ? cin0 : channels)) return MZMCTS_ERR_INVALID;
+        if ((reinterpret_cast<uintptr_t>(d.scale) | reinterpret_cast<uintptr_t>(d.shift)) & 15u)
+            return MZMCTS_ERR_INVALID;                   // (read four channels at a time)
         args.layer[l] = mz::TowerLayer{static_cast<const float*>(d.packed), d.scale, d.shift, d.export_raw, d.export_unit, d.cin, d.relu, d.skip, 0};
     }
     if (batch == 0) return MZMCTS_OK;
@@ -1141,7 +1146,8 @@ static int board_tower_split_impl(const float* x, const mz::TowerGather& gather,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
     // (4 boards per workgroup: 3 fill the MFMA rounds better -- 126 rows = 8 tiles -- and 2 let two workgroups share a
-    // CU, but both measured slower at 4096 Connect4 boards: 700 / 744 / 900 us per launch for 4 / 3 / 2)
+    // CU, but both measured slower at 4096 Connect4 boards: 700 / 744 / 900 us per launch for 4 / 3 / 2; again after the
+    // packed epilogue, 8192 boards with heads: 1289 us for 4, 1366 us for 3)
     if (height == 6 && width == 7) return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream, gather);
     if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream, gather);
     return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream, gather);

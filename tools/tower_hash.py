@@ -2,7 +2,7 @@
 """Regression aid for tower kernel work: recurrent inference of a game's residual network on fixed synthetic boards;
 prints SHA-256 of every output (a change that should be bit-neutral must leave them alone) and the tower's time per launch.
 
-    python tools/tower_hash.py [game=connect4] [boards for the hash=1001] [boards for the timing=8192]"""
+    [MZ_LIB=other/libmzmcts.so] python tools/tower_hash.py [game=connect4] [boards for the hash=1001] [boards for the timing=8192]"""
 import hashlib, importlib, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,9 @@ from parity_helpers import synthetic_model
 game = sys.argv[1] if len(sys.argv) > 1 else "connect4"
 n_hash = int(sys.argv[2]) if len(sys.argv) > 2 else 1001
 n_time = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+if os.environ.get("MZ_LIB"):                          # another build of the library (an A/B run against an earlier commit's)
+    for name in ("build", "_native"):
+        importlib.import_module("muzero-hypermodel_amd." + name).LIB_PATH = os.path.abspath(os.environ["MZ_LIB"])
 models = importlib.import_module("muzero-hypermodel_amd.models")
 config = importlib.import_module(f"muzero-hypermodel_amd.games.{game}").MuZeroConfig()
 model, _ = synthetic_model(models, config, "cuda")
