@@ -834,10 +834,12 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             advance();
         };
         auto fetch_b = [&](h8 (&b)[2][2], int it) {      // (two spare zero groups follow the last iteration's weights)
+#ifndef MZ_TOWER_NO_WLOAD                                 // (diagnostic builds: what the weight fetches cost)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) b[c][q] = wload(it, c, q);
+#endif
         };
         auto multiply = [&](const h8 (&a)[MTW][2], const h8 (&b)[2][2]) {
 #pragma unroll
