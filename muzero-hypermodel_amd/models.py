@@ -824,12 +824,9 @@ class MuZeroResidualNetwork(AbstractNetwork):
         c = dyn.conv.out_channels
         if len(state_shape) != 3 or state_shape[0] != c:
             return False
-        if c == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32":
-            # measured (one box, A/B): the 16-channel towers gain from gathering for themselves (84x84 config 27.8 -> 29.0 M
-            # simulations/s, TicTacToe 138.2 -> 138.6 M), the 64-channel split tower loses (Connect4 5.63 -> 5.49 M, also with the
-            # rows' addresses looked up once per thread: 10 KB of element-wise loads per sample from scattered rows are
-            # slower than the streaming gather kernel)
-            return False
+        # measured (one box, A/B): every tower gains from gathering for itself -- 84x84 config 27.8 -> 29.0 M simulations/s,
+        # TicTacToe 138.2 -> 138.6 M, Connect4 (64-channel split tower) 6.81 -> 7.02 M once its input fill walks planes with
+        # the rows' addresses in LDS (before that it lost: 5.63 -> 5.49 M).  MZ_TOWER_GATHER=off keeps the tensor form.
         h, w = int(state_shape[1]), int(state_shape[2])
         lib = _native.load()
         return (all(isinstance(conv, BoardConv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) for conv in convs)
