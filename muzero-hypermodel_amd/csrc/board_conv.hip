@@ -944,20 +944,39 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             if (L.export_raw) export_planes(L.export_raw);
             if (L.export_unit) {
                 __syncthreads();
-                for (int q = tid; q < n_samples * COUT; q += THREADS) {   // per plane: models.py:525-549
+                // per plane: models.py:525-549.  Two threads per plane (first / second half of its positions, all loads
+                // issued before the first compare); the halves' minima and maxima are combined in position order, so the
+                // result is the sequential scan's, signs of zero included.
+                constexpr int HALF = (P + 1) / 2;
+                for (int q = tid >> 1; q < n_samples * COUT; q += THREADS / 2) {
                     const int n = q % COUT, sidx = q / COUT;
-                    float lo_v = load_val(dst, CPO, sidx * PP + plane_pos(0), n), hi_v = lo_v;
-                    for (int p = 1; p < P; ++p) {
-                        const float v = load_val(dst, CPO, sidx * PP + plane_pos(p), n);
-                        lo_v = (v < lo_v || v != v) ? v : lo_v;
-                        hi_v = (v > hi_v || v != v) ? v : hi_v;
+                    const int second = tid & 1;
+                    float v[HALF];
+                    int at[HALF];
+#pragma unroll
+                    for (int k = 0; k < HALF; ++k) {
+                        const int p1 = HALF + k < P ? HALF + k : P - 1;          // (past the plane: masked below)
+                        at[k] = sidx * PP + (second ? plane_pos(p1) : plane_pos(k));
+                        v[k] = load_val(dst, CPO, at[k], n);
                     }
+                    float lo_v = v[0], hi_v = v[0];
+#pragma unroll
+                    for (int k = 1; k < HALF; ++k) {
+                        if (!second || HALF + k < P) {
+                            lo_v = (v[k] < lo_v || v[k] != v[k]) ? v[k] : lo_v;
+                            hi_v = (v[k] > hi_v || v[k] != v[k]) ? v[k] : hi_v;
+                        }
+                    }
+                    const float lo_o = __shfl_xor(lo_v, 1), hi_o = __shfl_xor(hi_v, 1);
+                    const float lo_a = second ? lo_o : lo_v, lo_b = second ? lo_v : lo_o;   // first half's, second half's
+                    const float hi_a = second ? hi_o : hi_v, hi_b = second ? hi_v : hi_o;
+                    lo_v = (lo_b < lo_a || lo_b != lo_b) ? lo_b : lo_a;
+                    hi_v = (hi_b > hi_a || hi_b != hi_b) ? hi_b : hi_a;
                     float span = hi_v - lo_v;
                     if (span < 1e-5f) span = span + 1e-5f;
-                    for (int p = 0; p < P; ++p) {
-                        const int pos = sidx * PP + plane_pos(p);
-                        store_val(dst, CPO, pos, n, (load_val(dst, CPO, pos, n) - lo_v) / span);
-                    }
+#pragma unroll
+                    for (int k = 0; k < HALF; ++k)
+                        if (!second || HALF + k < P) store_val(dst, CPO, at[k], n, (v[k] - lo_v) / span);
                 }
                 __syncthreads();
                 export_planes(L.export_unit);
