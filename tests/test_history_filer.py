@@ -67,3 +67,61 @@ def test_native_filer_matches_numpy_filing(pkg):
             assert all(np.array_equal(x, y) for x, y in zip(a.observation_history, b.observation_history))
         assert np.array_equal(filer.lengths(), ref._len)
     filer.close()
+
+
+def test_native_filer_with_per_move_legal_sets_and_players(pkg):
+    """mzhist_moves.legal_stride / num_legal_stride: a batch whose every move has its own legal set (board games,
+    engine.moves_inputs) and two players, filed in one call == the same moves filed one at a time with that move's set."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    E, L, shape, A, S, M = 600, 12, (3, 3, 3), 9, 25, 7
+    rs = np.random.RandomState(11)
+    first = rs.standard_normal((E,) + shape).astype(np.float32)
+    first_tp = rs.randint(0, 2, E).astype(np.int32)
+    whole, single = sp.HistoryFiler(E, L, shape, A), sp.HistoryFiler(E, L, shape, A)
+    whole.begin(first, first_tp)
+    single.begin(first, first_tp)
+    for batch in range(6):
+        moves_done = np.full(E, M, np.int32)
+        moves_done[rs.rand(E) < 0.2] = rs.randint(0, M, int((rs.rand(E) < 0.2).sum() or 1))[0]
+        num_legal = rs.randint(1, A + 1, (M, E)).astype(np.int32)
+        legal = np.stack([np.stack([rs.permutation(A) for _ in range(E)]) for _ in range(M)]).astype(np.int32)
+        visits = np.zeros((M, E, A), np.int32)
+        for m in range(M):
+            for e in range(0, E, 7):                                       # (a sparse fill keeps the test fast)
+                n = int(num_legal[m, e])
+                visits[m, e, :n] = rs.multinomial(S, np.full(n, 1.0 / n))
+        out = dict(moves_done=moves_done, actions=rs.randint(0, A, (M, E)).astype(np.int32), visits=visits,
+                   root_value_sum=rs.standard_normal((M, E)) * S)
+        rewards = rs.standard_normal((M, E)).astype(np.float32)
+        done = (rs.rand(M, E) < 0.2).astype(np.uint8)
+        lengths = whole.lengths().copy()
+        for m in range(M):
+            playing = moves_done > m
+            lengths = np.where(playing, lengths + 1, lengths)
+            done[m][(lengths >= L - 1) & playing] = 1
+            lengths = np.where((done[m] == 1) & playing, 0, lengths)
+        obs_after = rs.standard_normal((M, E) + shape).astype(np.float32)
+        obs_next = rs.standard_normal((M, E) + shape).astype(np.float32)
+        tp_after = rs.randint(0, 2, (M, E)).astype(np.int32)
+        tp_next = rs.randint(0, 2, (M, E)).astype(np.int32)
+
+        def games(b):
+            return [] if b is None else [(int(e), b.history(i)) for i, e in enumerate(b.env_index)]
+        got = games(whole.file(out, legal, num_legal, S, rewards, done, obs_after, obs_next, to_play_after=tp_after,
+                               to_play_next=tp_next))
+        want = []
+        for m in range(M):
+            one = dict(moves_done=(moves_done > m).astype(np.int32), actions=out["actions"][m][None], visits=visits[m][None],
+                       root_value_sum=out["root_value_sum"][m][None])
+            want += games(single.file(one, legal[m], num_legal[m], S, rewards[m][None], done[m][None], obs_after[m][None],
+                                      obs_next[m][None], to_play_after=tp_after[m][None], to_play_next=tp_next[m][None]))
+        assert len(got) == len(want) > 0
+        key = lambda item: (item[0], len(item[1].action_history), item[1].action_history)   # noqa: E731
+        for (ea, a), (eb, b) in zip(sorted(got, key=key), sorted(want, key=key)):
+            assert ea == eb and a.action_history == b.action_history and a.to_play_history == b.to_play_history
+            assert a.reward_history == b.reward_history and a.root_values == b.root_values
+            assert np.array_equal(np.array(a.child_visits), np.array(b.child_visits))
+            assert all(np.array_equal(x, y) for x, y in zip(a.observation_history, b.observation_history))
+        assert np.array_equal(whole.lengths(), single.lengths())
+    whole.close()
+    single.close()
