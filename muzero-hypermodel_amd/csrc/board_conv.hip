@@ -1101,9 +1101,10 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     // rows into 16-row tiles and every wavefront runs ceil(tiles / 8) of them per k-step: 16 x 9 = 144 rows = 9 tiles
     // cost two rounds for little more than one round's work.  With few boards that choice stands (more workgroups than
     // CUs matters most); with many, SB is the count whose rows fit ONE round and whose LDS lets two or more workgroups
-    // share a CU, so that one's fill / epilogue / export phases run under another's MFMAs: 12 x 9 = 108 rows = 7 tiles
-    // (measured at 65536 TicTacToe boards: SB 16 / 28 / 12 / 8 = 318 / 313 / 300 / 353 us per launch; 6x6, 16384 boards:
-    // SB 4 / 7 / 3 = 513 / 513 / 428 us).
+    // share a CU, so that one's fill / epilogue / export phases run under another's MFMAs: 14 x 9 = 126 rows = 8 tiles,
+    // a tile for every wavefront (measured at 65536 TicTacToe boards: SB 16 / 28 / 12 / 8 = 318 / 313 / 300 / 353 us per
+    // launch, and 12 -> 14: 374 -> 338 us with heads -- 12 x 9 = 108 rows are 7 tiles and leave the eighth wavefront
+    // idle; 6x6, 16384 boards: SB 4 / 7 / 3 = 513 / 513 / 428 us).
     const bool many = b >= 16384;
     if (height == 6 && width == 7) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 7, 4>(x, b, cin0, args, stream, gather);
@@ -1116,7 +1117,7 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
         return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream, gather);
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream, gather);
-    if (many) return mz::launch_board_tower<1, 3, 3, 12>(x, b, cin0, args, stream, gather);
+    if (many) return mz::launch_board_tower<1, 3, 3, 14>(x, b, cin0, args, stream, gather);
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream, gather);
 }
 

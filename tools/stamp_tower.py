@@ -38,7 +38,7 @@ with torch.no_grad():
         model.recurrent_inference_from_planes(planes, out_state=out_state)
     torch.cuda.synchronize()
     lib.mzmcts_tower_stamps(stamps, 1)
-per_wg = {"tictactoe": 12, "connect4": 4}.get(game, 4)    # boards per workgroup (board_conv.hip's dispatch at large batch)
+per_wg = {"tictactoe": 14, "connect4": 4}.get(game, 4)    # boards per workgroup (board_conv.hip's dispatch at large batch)
 names = ["zero LDS", "input fill", "main loops (MFMA)", "epilogues", "barrier after a layer", "exports + rescale"]
 vals = [int(stamps[i]) for i in range(6)]
 total = sum(vals) or 1
