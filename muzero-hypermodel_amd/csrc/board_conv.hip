@@ -339,34 +339,45 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         float4* z = reinterpret_cast<float4*>(lds);
         for (int i = tid; i < words / 4; i += THREADS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // gathered input: where sample q's hidden state starts in the pool, and its action plane's value (behind the buffers)
+    const float** in_row = reinterpret_cast<const float**>(lds + SB * PP * (cp0 + cp1));
+    float* act_plane = reinterpret_cast<float*>(in_row + SB);
+    if (gather.pool && tid < SB) {
+        const long long b = b0 + tid;
+        const bool present = tid < n_samples;
+        in_row[tid] = present ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden : nullptr;
+        act_plane[tid] = present ? static_cast<float>(gather.action[b]) / gather.action_space : 0.f;
+    }
     __syncthreads();
     MZ_TSTAMP(0);
     if (gather.pool) {
-        // input gathered from the hidden-state pool (+ the action plane): element i = (sample s, channel ci, position p)
-        const int count = n_samples * cin0 * P;
-        for (int i0 = tid; i0 < count; i0 += 4 * THREADS) {
-            float v[4];
-            int at[4];
+        // input gathered from the hidden-state pool (+ the action plane).  A thread keeps ONE board position and walks over
+        // the (sample, channel) planes, TPP planes per pass: consecutive threads read consecutive addresses of a row, the
+        // position's arithmetic is done once, the row's address comes from LDS instead of a parent-index load per element.
+        constexpr int TPP = THREADS / P;
+        if (tid < TPP * P) {
+            const int p = tid % P;
+            const int at_p = ((p / W + 1) * PW + (p % W) + 1) * cp0;
+            const int planes = n_samples * cin0;         // plane sc = sample * cin0 + channel
+            for (int sc0 = tid / P; sc0 < planes; sc0 += 4 * TPP) {
+                float v[4];
+                int at[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * THREADS;
-                at[k] = -1;
-                v[k] = 0.f;
-                if (i < count) {
-                    const int p = i % P;
-                    const int sc = i / P;
-                    const int s = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin0_magic));
-                    const int ci = sc - s * cin0;
-                    const long long b = b0 + s;
-                    v[k] = (ci * P < gather.hidden)
-                               ? gather.pool[(static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden + ci * P + p]
-                               : static_cast<float>(gather.action[b]) / gather.action_space;
-                    at[k] = (s * PP + (p / W + 1) * PW + (p % W) + 1) * cp0 + ci;
+                for (int k = 0; k < 4; ++k) {
+                    const int sc = sc0 + k * TPP;
+                    at[k] = -1;
+                    v[k] = 0.f;
+                    if (sc < planes) {
+                        const int s = static_cast<int>(__umulhi(static_cast<uint32_t>(sc), cin0_magic));
+                        const int ci = sc - s * cin0;
+                        v[k] = (ci * P < gather.hidden) ? in_row[s][ci * P + p] : act_plane[s];
+                        at[k] = s * PP * cp0 + at_p + ci;
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (at[k] >= 0) lds[at[k]] = v[k];
+                for (int k = 0; k < 4; ++k)
+                    if (at[k] >= 0) lds[at[k]] = v[k];
+            }
         }
     } else {
         const int count = n_samples * cin0 * P;
@@ -572,7 +583,7 @@ static int launch_board_tower(const float* x, int batch, int cin0, const TowerAr
     }
     cp0 = std::max(cp0, 16 * NT + 4);                     // outputs (16 NT channels) land in either buffer
     cp1 = std::max(cp1, 16 * NT + 4);
-    const size_t lds = sizeof(float) * static_cast<size_t>(SB) * PP * (cp0 + cp1);
+    const size_t lds = sizeof(float) * static_cast<size_t>(SB) * PP * (cp0 + cp1) + (sizeof(float*) + sizeof(float)) * SB;
     if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
     auto kernel = board_tower_kernel<NT, H, W, SB>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
