@@ -1,3 +1,8 @@
+"""Where does a board-game move batch spend its time?  TicTacToe with an FC-16 network, 32768 device envs,
+DeviceSelfPlay.play_moves(18): cProfile of the host side of five batches; under `rocprofv3 --kernel-trace --stats` the same
+run gives the kernel shares (profiles/r02_tictactoe_fc_batch_kernel_stats.csv).
+
+    python tools/profile_move_batches.py"""
 import cProfile, pstats, importlib, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sp = importlib.import_module("muzero-hypermodel_amd.self_play"); models = importlib.import_module("muzero-hypermodel_amd.models")
