@@ -26,7 +26,7 @@ def main():
     out_dir = os.path.join(ROOT, "tools", "_stamps")
     os.makedirs(out_dir, exist_ok=True)
     lib_path = os.path.join(out_dir, "libmzmcts.so")
-    cmd = [build._hipcc()] + build.HIPCC_FLAGS + ["-DMZ_STAMPS", "-fno-slp-vectorize", "-o", lib_path] + build.SOURCES
+    cmd = [build._hipcc()] + build.HIPCC_FLAGS + ["-shared", "-DMZ_STAMPS", "-fno-slp-vectorize", "-o", lib_path] + build.SOURCES
     subprocess.check_call(cmd, cwd=build.CSRC)
     build.LIB_PATH = lib_path
     native = importlib.import_module("muzero-hypermodel_amd._native")

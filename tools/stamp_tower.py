@@ -15,7 +15,7 @@ build = importlib.import_module("muzero-hypermodel_amd.build")
 out_dir = os.path.join(ROOT, "tools", "_stamps")
 os.makedirs(out_dir, exist_ok=True)
 lib_path = os.path.join(out_dir, "libmzmcts_tower.so")
-subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-DMZ_TOWER_STAMPS"] + ["-D" + e for e in extra] + ["-o", lib_path] + build.SOURCES, cwd=build.CSRC)
+subprocess.check_call([build._hipcc()] + build.HIPCC_FLAGS + ["-shared", "-DMZ_TOWER_STAMPS"] + ["-D" + e for e in extra] + ["-o", lib_path] + build.SOURCES, cwd=build.CSRC)
 native = importlib.import_module("muzero-hypermodel_amd._native")
 native.LIB_PATH = lib_path
 build.LIB_PATH = lib_path
