@@ -63,6 +63,7 @@ class BatchedMCTS:
         self._graph = None
         self._eager_searches = 0
         self._graph_model = None
+        self._graph_generation = 0
         self._profiling = False
         self._group_width = int(group_width)
         self.stream = None          # optional dedicated torch.cuda.Stream (PipelinedSearch)
@@ -365,7 +366,12 @@ class BatchedMCTS:
 
     def _run_simulations(self, model):
         graph_ok = self.use_graph and not self._profiling
-        if graph_ok and self._graph is not None and self._graph_model is model:
+        # (a captured loop holds the addresses of the network's tensors: weights.FlatWeights moving them into its flat
+        # buffer after the capture -- a first weight pull behind a first game -- makes the capture stale)
+        generation = getattr(model, "_storage_generation", 0)
+        if graph_ok and self._graph is not None and (self._graph_model is not model or self._graph_generation != generation):
+            self._graph = None
+        if graph_ok and self._graph is not None:
             self._check(self._lib.mzmcts_set_simulations_done(self._h, 0))
             self._graph.replay()
             self._check(self._lib.mzmcts_set_simulations_done(self._h, self.S))
@@ -376,7 +382,7 @@ class BatchedMCTS:
             torch.cuda.synchronize(self.device)
             with torch.cuda.graph(graph):
                 self._simulate_all(model)
-            self._graph, self._graph_model = graph, model
+            self._graph, self._graph_model, self._graph_generation = graph, model, generation
             self._check(self._lib.mzmcts_set_simulations_done(self._h, 0))
             graph.replay()
             self._check(self._lib.mzmcts_set_simulations_done(self._h, self.S))
@@ -769,10 +775,16 @@ class PipelinedLockstep:
         return slice(g * self.per_group, (g + 1) * self.per_group)
 
     def refresh(self):
-        """After a weight refresh of group 0's model: the other replicas follow."""
+        """After a weight refresh of group 0's model: the other replicas follow -- parameters AND the constants cached
+        from them (folded batch norms, packed / split tower weights), which a replayed hipGraph reads without ever
+        coming back to Python.  Queued on each group's own stream behind the refresh of group 0 (reference
+        self_play.py:37: every game that starts after the pull sees the pulled weights)."""
         state = self.models[0].state_dict()
-        for m in self.models[1:]:
-            m.load_state_dict(state)
+        current = torch.cuda.current_stream(self.engines[0].device)
+        for eng, m in zip(self.engines[1:], self.models[1:]):
+            eng.stream.wait_stream(current)
+            with torch.cuda.stream(eng.stream):
+                m.set_weights(state)
 
     def begin(self, g, observations, legal, to_play, add_exploration_noise=True, num_legal=None):
         eng = self.engines[g]

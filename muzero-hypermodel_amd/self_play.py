@@ -1127,9 +1127,14 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
 
     def _pull_weights(self, shared_storage, version):
         ManyEnvLoop._pull_weights(self, shared_storage, version)     # group 0's model (all ranks: one flat broadcast)
+        # the replicas take the parameters AND rebuild what they cache from them (folded batch norms, packed tower
+        # weights): a replayed hipGraph reads those buffers without coming back to Python
         state = self.model.state_dict()
-        for actor in self.actors[1:]:
-            actor.model.load_state_dict(state)
+        current = torch.cuda.current_stream(self.device)
+        for actor, stream in zip(self.actors[1:], self.streams[1:]):
+            stream.wait_stream(current)
+            with torch.cuda.stream(stream):
+                actor.model.set_weights(state)
 
     @property
     def moves_played(self):

@@ -38,6 +38,10 @@ class FlatWeights:
                 view = self.flat[self.offsets[k]: self.offsets[k] + t.numel()].view(t.shape)
                 view.copy_(t)
                 t.data = view  # re-point the parameter / buffer at the flat storage
+        # the tensors moved: anything that recorded their addresses (a captured hipGraph, packed constants) is stale
+        model._storage_generation = getattr(model, "_storage_generation", 0) + 1
+        if hasattr(model, "refresh_inference_constants") and device.type == "cuda":
+            model.refresh_inference_constants()
 
     def nbytes(self):
         return self.numel * 4
