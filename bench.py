@@ -150,15 +150,34 @@ def launch_ranks(args, argv):
         child_env = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=child_env,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True))
-    line = procs[0].stdout.read()
-    codes = []
-    deadline = time.time() + 3400
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(-9)
+    # rank 0's stdout is drained by a thread: a rank that hangs or dies at the rendezvous keeps the others (and rank 0's
+    # pipe) open for ever, and a blocking read here would never reach the deadline below
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MZ_BENCH_LAUNCH_DEADLINE_S", "3400"))
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = any(c not in (None, 0) for c in codes)
+        if failed or time.time() > deadline:
+            # the first rank to fail (or the deadline) ends the job: the others would wait in a collective for ever
+            grace = time.time() + (5.0 if failed else 0.0)
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=max(0.0, grace - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+                        codes[i] = -9
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    line = "".join(chunks)
     for row in line.splitlines():                           # ONE JSON line on stdout; anything else a rank printed -> stderr
         print(row, file=sys.stdout if row.startswith("{") else sys.stderr, flush=True)
     bad = [c for c in codes if c != 0]
@@ -430,6 +449,8 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
+    if os.environ.get("MZ_BENCH_FAULT_RANK") is not None and os.environ.get("MZ_BENCH_FAULT_RANK") == os.environ.get("RANK"):
+        sys.exit(3)                                          # fault injection for tests/test_bench_launcher.py: a rank that dies before the rendezvous
     if args.rehearse_cpu:
         return rehearse_cpu(args)
     cpu_helper = None

@@ -102,13 +102,22 @@ int mzhist_file(mzhist* h, const mzhist_moves* mv, int32_t* n_finished) {
     };
     // pass 1: how many games end per env, and how long the longest of them is
     std::atomic<int> longest{0};
-    std::atomic<bool> overflow{false};
+    std::atomic<bool> overflow{false}, bad_legal{false};
     for_envs([&](int lo, int hi) {
         int local_longest = 0;
         for (int e = lo; e < hi; ++e) {
             int len = h->length[e], count = 0;
             const int k = std::min(mv->moves_done[e], M);
             for (int m = 0; m < k; ++m) {
+                // the legal sets come back from the device: nothing of them is used as an index before it was checked
+                const int32_t* legal = reinterpret_cast<const int32_t*>(at(mv->legal, mv->legal_stride, m)) + static_cast<size_t>(e) * A;
+                const int n_legal = reinterpret_cast<const int32_t*>(at(mv->num_legal, mv->num_legal_stride, m))[e];
+                if (n_legal < 0 || n_legal > A) {
+                    bad_legal.store(true);
+                } else {
+                    for (int i = 0; i < n_legal; ++i)
+                        if (legal[i] < 0 || legal[i] >= A) bad_legal.store(true);
+                }
                 ++len;
                 if (len > h->L) overflow.store(true);
                 if (mv->done[static_cast<size_t>(m) * E + e]) {
@@ -123,6 +132,10 @@ int mzhist_file(mzhist* h, const mzhist_moves* mv, int32_t* n_finished) {
         while (local_longest > seen && !longest.compare_exchange_weak(seen, local_longest)) {
         }
     });
+    if (bad_legal.load()) {
+        h->error = "mzhist_file: a legal-action count outside [0, A] or a legal action outside [0, A)";
+        return -1;
+    }
     if (overflow.load()) {
         h->error = "mzhist_file: a game outgrew max_moves";
         return -1;

@@ -104,8 +104,36 @@ class Trainer:
                 f"{self.config.optimizer} is not implemented. You can change the optimizer manually in trainer.py.")
         if self._graph_mode and (self.config.optimizer != "Adam" or torch.device(device).type != "cuda"):
             raise NotImplementedError("Trainer(graph=True) captures an Adam step on the GPU")
+        self._lr_host = float(self.config.lr_init)
         if initial_checkpoint.get("optimizer_state") is not None:
-            self.optimizer.load_state_dict(copy.deepcopy(initial_checkpoint["optimizer_state"]))
+            self.optimizer.load_state_dict(copy.deepcopy(self._portable_optimizer_state(initial_checkpoint["optimizer_state"])))
+            saved_lr = self.optimizer.param_groups[0]["lr"]
+            self._lr_host = float(saved_lr)
+            if self._graph_mode:
+                # load_state_dict replaced every param group's settings with the checkpoint's: put the device-resident
+                # learning rate and the capturable flag back (an eager checkpoint carries a float lr, capturable False and
+                # CPU step counters; a graphed one a tensor lr), or update_lr() would fill an orphaned tensor and the
+                # capture of optimizer.step() would break / bake the learning rate in
+                self._lr.fill_(self._lr_host)
+                dev = self._lr.device
+                for group in self.optimizer.param_groups:
+                    group["lr"], group["capturable"] = self._lr, True
+                for state in self.optimizer.state.values():
+                    if "step" in state:
+                        state["step"] = torch.as_tensor(state["step"], dtype=torch.float32).to(dev).reshape(())
+
+    @staticmethod
+    def _portable_optimizer_state(state):
+        """An optimizer state dict whose param groups hold plain numbers (a graphed trainer's learning rate is a device
+        tensor shared by every group: a checkpoint must not alias it)."""
+        out = dict(state)
+        out["param_groups"] = [{k: (float(v) if torch.is_tensor(v) and v.numel() == 1 and k == "lr" else v)
+                                for k, v in group.items()} for group in state["param_groups"]]
+        return out
+
+    def optimizer_state(self):
+        """optimizer.state_dict() on the CPU with a float learning rate: what goes into a checkpoint (trainer.py:87-95)."""
+        return copy.deepcopy(models.dict_to_cpu(self._portable_optimizer_state(self.optimizer.state_dict())))
 
     # ---- the loop (trainer.py:62-122) without Ray ----------------------------------------------------
     def continuous_update_weights(self, replay_buffer, shared_storage, max_steps=None):
@@ -120,10 +148,10 @@ class Trainer:
                 replay_buffer.update_priorities(priorities, index_batch)
             if self.training_step % self.config.checkpoint_interval == 0:
                 shared_storage.set_info({"weights": copy.deepcopy(self.model.get_weights()),
-                                         "optimizer_state": copy.deepcopy(models.dict_to_cpu(self.optimizer.state_dict()))})
+                                         "optimizer_state": self.optimizer_state()})
                 if self.config.save_model:               # trainer.py:96-97
                     shared_storage.save_checkpoint()
-            shared_storage.set_info({"training_step": self.training_step, "lr": self.optimizer.param_groups[0]["lr"],
+            shared_storage.set_info({"training_step": self.training_step, "lr": self._lr_host,
                                      "total_loss": total_loss, "value_loss": value_loss, "reward_loss": reward_loss,
                                      "policy_loss": policy_loss})
             done += 1
@@ -270,6 +298,7 @@ class Trainer:
 
     def update_lr(self):
         lr = self.config.lr_init * self.config.lr_decay_rate ** (self.training_step / self.config.lr_decay_steps)
+        self._lr_host = float(lr)              # what set_info publishes: a Python float, as in the reference
         if self._graph_mode:
             self._lr.fill_(lr)
             return

@@ -50,3 +50,17 @@ def test_bench_without_gpus_fails_loudly():
     proc = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2"], cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=300)
     assert proc.returncode != 0 and "needs MI355X GPUs" in proc.stderr
+
+
+def test_bench_launcher_ends_when_a_rank_dies_before_the_rendezvous():
+    """A rank that dies at start leaves rank 0 waiting in the rendezvous with its stdout open: the launcher must not
+    block on that pipe -- it notices the failed rank, ends the others and exits non-zero in bounded time."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MZ_BENCH_FAULT_RANK"] = "1"
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-cpu", "--steps", "4"], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=120)
+    assert proc.returncode != 0
+    assert time.time() - t0 < 60
+    assert not [line for line in proc.stdout.splitlines() if line.startswith("{")]      # no result line from a failed job

@@ -129,3 +129,57 @@ def test_graphed_step_equals_eager_step(mods, pkg):
     print(f"graphed vs eager: weights {worst_w:.2e}, priorities {worst_p:.2e}, losses {worst_l:.2e} (rel.)")
     # (priorities are sqrt(|predicted - target|): steep at 0, so a 1e-7 difference in a weight shows as ~3e-4 there)
     assert worst_w <= 1e-5 and worst_l <= 1e-5 and worst_p <= 2e-3
+
+
+@pytest.mark.parametrize("first", ["eager", "graphed"])
+def test_graphed_trainer_resumes_from_a_checkpoint(mods, pkg, first):
+    """Trainer(graph=True) built from a checkpoint's optimizer_state -- written by an eager trainer (float learning
+    rate, capturable False, CPU step counters) or by a graphed one (device learning rate) -- keeps its device-resident
+    learning rate and the capturable flag (load_state_dict would otherwise replace both with the checkpoint's and the
+    decay would stop), and continues like an eager trainer resumed from the same checkpoint."""
+    trainer_mod, models = mods
+    config = importlib.import_module("muzero-hypermodel_amd.games.cartpole").MuZeroConfig()
+    config.lr_decay_steps = 4                      # a decay that shows within a few steps
+    model = models.MuZeroNetwork(config)
+    ckpt = {"weights": model.get_weights(), "training_step": 0, "optimizer_state": None}
+    B, K1, A = 32, config.num_unroll_steps + 1, len(config.action_space)
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def batch():
+        return (torch.rand((B,) + tuple(config.observation_shape), generator=g, device="cuda"),
+                torch.randint(0, A, (B, K1), generator=g, device="cuda"),
+                torch.randn(B, K1, generator=g, device="cuda") * 10, torch.randn(B, K1, generator=g, device="cuda"),
+                torch.softmax(torch.randn(B, K1, A, generator=g, device="cuda"), dim=2),
+                torch.rand(B, generator=g, device="cuda") + 0.5,
+                torch.randint(1, K1 + 1, (B, K1), generator=g, device="cuda").float())
+
+    batches = [batch() for _ in range(6)]
+    writer = trainer_mod.Trainer(ckpt, config, device="cuda", graph=(first == "graphed"))
+    for bt in batches[:3]:
+        writer.update_lr()
+        writer.update_weights(bt)
+    saved = {"weights": writer.model.get_weights(), "training_step": writer.training_step,
+             "optimizer_state": writer.optimizer_state()}
+    assert isinstance(saved["optimizer_state"]["param_groups"][0]["lr"], float)     # a checkpoint aliases no live tensor
+    assert isinstance(writer._lr_host, float)
+    runs = {}
+    for graph in (False, True):
+        trainer = trainer_mod.Trainer(saved, config, device="cuda", graph=graph)
+        assert trainer.training_step == 3
+        lrs, out = [], []
+        for bt in batches[3:]:
+            trainer.update_lr()
+            group = trainer.optimizer.param_groups[0]
+            lrs.append(float(group["lr"]))
+            if graph:
+                assert group["lr"] is trainer._lr and group["capturable"] is True
+            out.append(trainer.update_weights(bt))
+        want = [config.lr_init * config.lr_decay_rate ** (s / config.lr_decay_steps) for s in (3, 4, 5)]
+        assert np.allclose(lrs, want, rtol=1e-6), (lrs, want)                       # the decay goes on after a resume
+        steps = [float(torch.as_tensor(st["step"])) for st in trainer.optimizer.state.values()]
+        assert steps and all(s == 6.0 for s in steps)                                # Adam's step counters carried over
+        runs[graph] = (out, {k: v.clone() for k, v in trainer.model.state_dict().items()})
+    (eager, w_eager), (graphed, w_graphed) = runs[False], runs[True]
+    worst_w = max(float((w_eager[k] - w_graphed[k]).abs().max()) for k in w_eager)
+    worst_l = max(abs(x - y) / abs(x) for a, b in zip(eager, graphed) for x, y in zip(a[1:], b[1:]))
+    assert worst_w <= 1e-5 and worst_l <= 1e-5, (worst_w, worst_l)

@@ -125,3 +125,30 @@ def test_native_filer_with_per_move_legal_sets_and_players(pkg):
         assert np.array_equal(whole.lengths(), single.lengths())
     whole.close()
     single.close()
+
+
+def test_native_filer_rejects_legal_sets_outside_the_action_space(pkg):
+    """The legal sets of a batch are copied back from the device: a count outside [0, A] or an action outside [0, A)
+    is an error (RuntimeError with the library's message), never an out-of-bounds write into a history row; the rows
+    are left untouched and a clean batch files afterwards."""
+    import pytest
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    E, L, shape, A, S, M = 8, 10, (1, 1, 4), 3, 10, 2
+    rs = np.random.RandomState(1)
+    filer = sp.HistoryFiler(E, L, shape, A)
+    filer.begin(rs.standard_normal((E,) + shape).astype(np.float32))
+    out = dict(moves_done=np.full(E, M, np.int32), actions=rs.randint(0, A, (M, E)).astype(np.int32),
+               visits=rs.multinomial(S, [0.5, 0.3, 0.2], (M, E)).astype(np.int32), root_value_sum=rs.standard_normal((M, E)))
+    rewards, done = np.zeros((M, E), np.float32), np.zeros((M, E), np.uint8)
+    obs = rs.standard_normal((M, E) + shape).astype(np.float32)
+    good_legal, good_n = np.tile(np.arange(A, dtype=np.int32), (E, 1)), np.full(E, A, np.int32)
+    for legal, n in ((good_legal, np.where(np.arange(E) == 5, A + 1, A).astype(np.int32)),
+                     (good_legal, np.where(np.arange(E) == 2, -1, A).astype(np.int32)),
+                     (np.where(np.arange(E)[:, None] == 3, 7, good_legal).astype(np.int32), good_n),
+                     (np.where(np.arange(E)[:, None] == 0, -2, good_legal).astype(np.int32), good_n)):
+        with pytest.raises(RuntimeError, match="legal"):
+            filer.file(out, legal, n, S, rewards, done, obs, obs)
+        assert (filer.lengths() == 0).all()
+    assert filer.file(out, good_legal, good_n, S, rewards, done, obs, obs) is None
+    assert (filer.lengths() == M).all()
+    filer.close()
