@@ -27,7 +27,9 @@ def golden():
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (its directory name has a hyphen, so import it by string)."""
+    """The product package (its directory name has a hyphen, so import it by string), its native library up to date
+    with the sources (per-object rebuild: a no-op when nothing changed)."""
+    importlib.import_module("muzero-hypermodel_amd.build").build_native()
     return importlib.import_module("muzero-hypermodel_amd")
 
 
