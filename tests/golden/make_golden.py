@@ -461,16 +461,22 @@ def _history_arrays(gh, A):
     )
 
 
-def g6_play_game(ctx):
+def g6_play_game(ctx, only=None):
     models, self_play, cfgs = ctx["models"], ctx["self_play"], ctx["configs"]
     import games.connect4 as c4
     import games.tictactoe as ttt
     plans = [
-        ("tictactoe", ttt.Game, [(s, 1.0, None, "self", 0) for s in range(4)]
+        ("tictactoe", "tictactoe", ttt.Game, [(s, 1.0, None, "self", 0) for s in range(4)]
          + [(10, 0, None, "expert", 0), (11, 0, None, "random", 1), (12, 1.0, 4, "self", 0)]),
-        ("connect4", c4.Game, [(s, 1.0, None, "self", 0) for s in range(2)]),
+        ("connect4", "connect4", c4.Game, [(s, 1.0, None, "self", 0) for s in range(2)]),
+        # round 3: Connect4 test-mode games (SelfPlay.select_opponent_action, self_play.py:189-221, against
+        # games/connect4.py:306-343's expert; MuZero as either player; a random opponent) and the temperature threshold
+        ("connect4_opponents", "connect4", c4.Game, [(20, 0, None, "expert", 0), (21, 0, None, "expert", 1),
+                                                     (22, 0, None, "random", 1), (23, 1.0, 6, "self", 0)]),
     ]
-    for name, Game, runs in plans:
+    for fixture, name, Game, runs in plans:
+        if only is not None and fixture not in only:
+            continue
         config = cfgs[name]
         A = len(config.action_space)
         tmpl = models.MuZeroNetwork(config).state_dict()
@@ -488,11 +494,15 @@ def g6_play_game(ctx):
                  {"self": 0, "expert": 1, "random": 2}[opponent], mzp], dtype="float64")
             out[f"run{i}_rng_pos_end"] = int(st[2])
             out[f"run{i}_rng_next_word"] = int(numpy.random.randint(0, 2**31 - 1))
-            print(f"   {name} run{i} seed={seed} opp={opponent}: {len(gh.action_history)-1} moves"
+            print(f"   {fixture} run{i} seed={seed} opp={opponent}: {len(gh.action_history)-1} moves"
                   f" in {time.time()-t0:.1f}s")
         out["n_runs"] = len(runs)
         out.update(config_scalars(config))
-        save(f"g6_{name}_games", **out)
+        save(f"g6_{fixture}_games", **out)
+
+
+def g6_connect4_opponents(ctx):
+    g6_play_game(ctx, only=("connect4_opponents",))
 
 
 def g7_rng(ctx):
@@ -841,8 +851,10 @@ def g16_trainer_resnet(ctx):
         priorities, total, v, r, p = tr.update_weights(batch)
         out[f"priorities{step}"] = numpy.asarray(priorities, dtype="float32")
         out[f"losses{step}"] = numpy.array([total, v, r, p], dtype="float64")
-    for k, t in tr.model.get_weights().items():          # weights (and BatchNorm running statistics) after both steps
-        out[f"w1_{k}"] = t.detach().cpu().numpy().copy()
+        for k, t in tr.model.get_weights().items():      # weights (and BatchNorm running statistics) after the step
+            out[f"w{step}_{k}"] = t.detach().cpu().numpy().copy()
+        for k, prm in tr.model.named_parameters():       # round 3: the gradients the step was made from (still in .grad)
+            out[f"g{step}_{k}"] = prm.grad.detach().cpu().numpy().copy()
     save("g16_trainer_tictactoe", **out)
 
 
@@ -979,7 +991,7 @@ def make_configs():
 
 
 ALL = [g0_weights, g1_support_to_scalar, g2_fc_inference, g3_resnet_inference, g4_cartpole,
-       g5_tictactoe, g5_connect4, g5_atari84, g5_degenerate, g6_play_game, g7_rng, g8_select_action,
+       g5_tictactoe, g5_connect4, g5_atari84, g5_degenerate, g6_play_game, g6_connect4_opponents, g7_rng, g8_select_action,
        g9_stacked, g10_reference_speed, g11_envs, g12_replay_targets, g12_reference_speed, g13_reanalyse, g14_trainer, g15_self_play_loop, g16_trainer_resnet]
 
 

@@ -432,7 +432,10 @@ def test_gpu_network_outputs_vs_reference_fixtures(models_mod):
                                                        torch.from_numpy(fx["actions"]).cuda())
         for got, key in ((v0, "init_value"), (p0, "init_policy"), (h0, "init_hidden"), (v1, "rec_value"),
                          (r1, "rec_reward"), (p1, "rec_policy"), (h1, "rec_hidden")):
-            tol = 1e-5 if loader == "fc" else 2e-5       # (hidden states are min-max rescaled: small spans amplify)
+            # the north star's bar on every network output: logits within 1e-5 of the reference's (measured worst over the
+            # four networks 1.4e-6).  Hidden states are (x - min) / (max - min) per board plane: an error e in x, min and
+            # max shows as up to 3 e / span, so they get 2e-5 (measured worst 7.3e-6, TicTacToe's recurrent state)
+            tol = 2e-5 if key.endswith("hidden") and loader != "fc" else 1e-5
             np.testing.assert_allclose(got.cpu().numpy(), fx[key], rtol=tol, atol=tol, err_msg=f"{name}:{key}")
 
 
@@ -565,19 +568,38 @@ def test_mcts_run_override_root_with(eng, models_mod, pkg):
     mcts.close()
 
 
-def test_self_play_games_vs_reference_g6(eng, models_mod, pkg):
-    """SelfPlay.play_game on TicTacToe with the synthetic weights: trajectories recorded from the
-    reference (seeds 0-3 self-play, expert / random opponents, temperature threshold)."""
+# Searches of recorded games whose visit counts may leave the reference's by ONE simulation (a UCB near-tie decided the
+# other way by the last bits of the network's outputs), the sampled action staying the reference's: (fixture, tower
+# precision) -> {run: [move indices]}.  Measured on MI355X; with the exact-fp32 towers every game is exact.
+G6_NEAR_TIES = {("g6_connect4_opponents_games", "split"): {2: [5]}}
+
+
+@pytest.mark.parametrize("fixture,game,precision", [
+    ("g6_tictactoe_games", "tictactoe", "split"), ("g6_connect4_games", "connect4", "split"),
+    ("g6_connect4_games", "connect4", "fp32"), ("g6_connect4_opponents_games", "connect4", "split"),
+    ("g6_connect4_opponents_games", "connect4", "fp32")])
+def test_self_play_games_vs_reference_g6(eng, models_mod, pkg, monkeypatch, fixture, game, precision):
+    """SelfPlay.play_game (self_play.py:110-184) with the synthetic weights against trajectories recorded from the
+    reference: TicTacToe (seeds 0-3 self-play, expert / random opponents, temperature threshold), Connect4 self-play
+    (200 simulations per move through the split-precision tower) and Connect4 test-mode games -- the expert of
+    games/connect4.py:306-343 as either player, a random opponent (select_opponent_action, self_play.py:189-221), and
+    the temperature threshold.  Every game must be reproduced move for move, with the policy targets bit for bit, the
+    value targets within the residual networks' bar, and the global RNG left where the reference left it.  Connect4's
+    64-channel towers run in both forms: `split` (two fp16 halves per operand, the default) and `fp32` (exact-fp32 MFMA);
+    the searches listed in G6_NEAR_TIES may move one simulation between two children."""
+    monkeypatch.setenv("MZ_BOARD_CONV_PRECISION", precision)
+    near_ties = G6_NEAR_TIES.get((fixture, precision), {})
     sp = importlib.import_module("muzero-hypermodel_amd.self_play")
-    ttt = games("tictactoe")
-    config = ttt.MuZeroConfig()
+    mod = games(game)
+    config = mod.MuZeroConfig()
+    A = len(config.action_space)
     _, weights = synthetic_model(models_mod, config, "cpu")
-    fx = load_golden("g6_tictactoe_games")
+    fx = load_golden(fixture)
     full, total = 0, int(fx["n_runs"])
     for i in range(total):
         seed, temp, thr, opp, mzp = fx[f"run{i}_args"]
         opponent = {0: "self", 1: "expert", 2: "random"}[int(opp)]
-        actor = sp.SelfPlay({"weights": weights}, ttt.Game, config, int(seed))
+        actor = sp.SelfPlay({"weights": weights}, mod.Game, config, int(seed))
         gh = actor.play_game(float(temp), None if thr < 0 else int(thr), False, opponent, int(mzp))
         actor.close_game()
         ref_actions = fx[f"run{i}_actions"].tolist()
@@ -592,13 +614,28 @@ def test_self_play_games_vs_reference_g6(eng, models_mod, pkg):
             full += 1
             assert gh.reward_history == fx[f"run{i}_rewards"].tolist()
             assert gh.to_play_history == fx[f"run{i}_to_play"].tolist()
-            got_cv = np.array(gh.child_visits, dtype=np.float64).reshape(-1, 9)
-            assert np.array_equal(got_cv, fx[f"run{i}_child_visits"])
+            got_cv = np.array(gh.child_visits, dtype=np.float64).reshape(-1, A)
+            ref_cv = fx[f"run{i}_child_visits"]
             got_rv = np.array([np.nan if v is None else v for v in gh.root_values])
-            np.testing.assert_allclose(got_rv, fx[f"run{i}_root_values"], rtol=RESNET_TOL["value_tol"],
+            ref_rv = fx[f"run{i}_root_values"].copy()
+            flipped = [m for m in range(len(got_cv)) if not np.array_equal(got_cv[m], ref_cv[m])]
+            assert flipped == [m for m in near_ties.get(i, []) if m in flipped], (i, flipped)     # only listed searches
+            searched = np.flatnonzero(~np.isnan(ref_rv))          # (opponent moves store no statistics: root value None)
+            for m in flipped:
+                # one simulation went to another child: two policy-target entries move by 1 / S, the root value by one
+                # leaf evaluation out of S
+                delta = np.abs(got_cv[m] - ref_cv[m]) * config.num_simulations
+                assert sorted(np.round(delta).tolist())[-3:] == [0.0, 1.0, 1.0] and abs(delta.sum() - 2.0) < 1e-9
+                at = searched[m]
+                assert abs(got_rv[at] - ref_rv[at]) <= 4.0 / config.num_simulations        # (|leaf values| stay below 2 here)
+                got_rv[at] = ref_rv[at]
+            np.testing.assert_allclose(got_rv, ref_rv, rtol=RESNET_TOL["value_tol"],
                                        atol=RESNET_TOL["value_tol"], equal_nan=True)
+            assert np.array_equal(np.array(gh.observation_history, dtype=np.float32), fx[f"run{i}_observations"])
             assert int(np.random.randint(0, 2**31 - 1)) == int(fx[f"run{i}_rng_next_word"])
-    print(f"games reproduced move for move: {full}/{total}")
+        else:
+            print(f"{fixture} run {i} ({opponent}): left the reference's game at move {agree} of {len(ref_actions) - 1}")
+    print(f"{fixture}: games reproduced move for move: {full}/{total}")
     assert full == total, f"only {full}/{total} games reproduced move for move (measured on MI355X: all of them)"
 
 

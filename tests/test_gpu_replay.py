@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from parity_helpers import load_golden
 from test_oracle_replay import NAMES, cfg_of, games_of
@@ -147,21 +148,109 @@ def test_reanalyse_values_and_targets(pkg):
 
 
 def test_trainer_on_device_matches_reference(pkg):
-    """Trainer.update_weights on the MI355X from CUDA-tensor batches vs the reference's CPU run (fixture G14)."""
+    """Trainer.update_weights on the MI355X from CUDA-tensor batches vs the reference's CPU run (fixture G14, CartPole
+    FC network, two Adam steps): learning rates equal, losses to 1e-5, and EVERY weight within 2e-6 of the reference's
+    after each step (measured: 3e-7).  Adam's first steps are lr * g / (|g| + eps) -- the sign of the gradient -- so this
+    also says that no gradient of this network is zero up to rounding."""
     from test_trainer_cpu import run_steps
     fx = load_golden("g14_trainer_cartpole")
     tr, out = run_steps(pkg, fx, "cuda", True)
     assert next(tr.model.parameters()).is_cuda
     for step, (lr, priorities, losses, weights) in enumerate(out):
         assert lr == float(fx[f"lr{step}"])
-        np.testing.assert_allclose(losses, fx[f"losses{step}"], rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(priorities, fx[f"priorities{step}"], rtol=2e-3, atol=2e-3)
-        # Adam's first steps move every weight by ~lr * sign(gradient): a gradient that is zero up to rounding may
-        # flip its sign between the CPU and the GPU kernels, so compare entry-wise with that in mind
-        close = total = 0
+        np.testing.assert_allclose(losses, fx[f"losses{step}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(priorities, fx[f"priorities{step}"], rtol=2e-3, atol=2e-3)   # sqrt(|.|): steep at 0
         for k, got in weights.items():
-            diff = np.abs(got - fx[f"w{step}_{k}"])
-            assert diff.max() <= 2.1 * lr * (step + 1), k
-            close += int((diff <= 1e-4).sum())
-            total += diff.size
-        assert close >= 0.97 * total, f"{close}/{total} weights agree after step {step}"
+            assert np.abs(got - fx[f"w{step}_{k}"]).max() <= 2e-6, (step, k)
+
+
+def test_resnet_trainer_on_device_matches_reference(pkg):
+    """Fixture G16 on the MI355X: two Trainer steps on the TicTacToe residual network (trainer.py:124-298; training-mode
+    BatchNorm, 3x3 / 1x1 convolutions forward and backward through PyTorch-ROCm, 20 unrolled positions).
+
+    What can differ from the reference's CPU run, and why -- each asserted:
+    * the unroll is a 20-fold iteration of dynamics + per-plane min-max rescale under batch statistics, and for these
+      weights it amplifies a rounding difference by < 2x per unrolled position (measured 1.8x: 2e-6 at the root, 0.4 at
+      position 20).  So the logits of position k agree with the CPU run of the same modules (which the CPU suite pins to
+      the reference at 2e-6) within 1e-5 * 2^k, the first positions at 1e-5;
+    * hence the losses agree to 5e-4 relative (measured 1.4e-4) and a gradient to a few percent of its tensor's largest
+      entry (measured <= 6.2 %);
+    * Adam's first step moves a weight by lr * g / (|g| + eps) = lr * sign(g): after step 0 an entry may leave the
+      reference's weight ONLY if the reference's own gradient (recorded in the fixture) is below 10 % of its tensor's
+      largest -- small enough for the deviation above to flip its sign -- and then by at most 2 lr; every other entry
+      agrees to 1e-6.  Measured: 243 of 21 715 entries, largest relative gradient among them 4 %;
+    * after step 1 (weights one flipped step apart) the tensors follow the reference's update as in the CPU test."""
+    from synth import synthetic_state_dict
+    from test_trainer_cpu import batch_of
+    fx = load_golden("g16_trainer_tictactoe")
+    tr_mod = importlib.import_module("muzero-hypermodel_amd.trainer")
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    config.batch_size = 24
+    template = models.MuZeroNetwork(config).state_dict()
+    weights = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(template, 0).items()}
+
+    def trainer(device):
+        return tr_mod.Trainer({"weights": {k: v.clone() for k, v in weights.items()}, "training_step": 0,
+                               "optimizer_state": None}, config, device=device)
+
+    def batch(device):
+        return tuple(b.to(device) if torch.is_tensor(b) else b for b in batch_of(fx, True))
+
+    # the unroll, position by position, against the CPU run of the same modules
+    logits = {}
+    for device in ("cpu", "cuda"):
+        tr = trainer(device)
+        b = tr._batch_on_device(batch(device))
+        logits[device] = [[t.detach().double().cpu() for t in step] for step in tr._unroll(b["observations"], b["actions"])]
+    growth = []
+    for k, (cpu_step, gpu_step) in enumerate(zip(logits["cpu"], logits["cuda"])):
+        worst = 0.0
+        for x, y in zip(cpu_step, gpu_step):
+            finite = torch.isfinite(x)                       # (the root position's reward logits are log(one_hot))
+            worst = max(worst, float((x[finite] - y[finite]).abs().max()))
+        growth.append(worst)
+        assert worst <= 1e-5 * 2.0 ** k, (k, worst)
+    assert max(growth[:3]) <= 1e-5
+    print("logit deviation per unrolled position:", " ".join(f"{g:.1e}" for g in growth))
+
+    tr = trainer("cuda")
+    lr = float(config.lr_init)
+    for step in range(2):
+        tr.update_lr()
+        assert tr._lr_host == float(fx[f"lr{step}"])
+        priorities, total, v, r, p = tr.update_weights(batch("cuda"))
+        grads = {k: prm.grad.detach().cpu().numpy() for k, prm in tr.model.named_parameters()}
+        got_w = {k: t.detach().cpu().numpy() for k, t in tr.model.get_weights().items()}
+        # (step 1 runs on weights of which ~1 % sit 2 lr away from the reference's, through the same 20-fold unroll:
+        # measured 0.9 % on the losses)
+        np.testing.assert_allclose([total, v, r, p], fx[f"losses{step}"], rtol=5e-4 if step == 0 else 2e-2)
+        if step == 0:
+            off = total_entries = 0
+            for k, g_gpu in grads.items():
+                g_ref = fx[f"g0_{k}"]
+                scale = float(np.abs(g_ref).max())
+                assert np.abs(g_gpu - g_ref).max() <= 0.1 * scale, k               # measured <= 6.2 %
+                dev = np.abs(got_w[k] - fx[f"w0_{k}"])
+                moved = dev > 1e-6
+                assert (np.abs(g_ref)[moved] <= 0.1 * scale).all(), k               # only sign-flippable entries leave
+                assert dev.max() <= 2 * lr + 1e-6, k
+                off += int(moved.sum())
+                total_entries += dev.size
+            print(f"entries that left the reference's weights after step 0: {off} of {total_entries}")
+            assert off <= 0.03 * total_entries
+        else:
+            worst = 0.0
+            for k, got in got_w.items():
+                want = fx[f"w1_{k}"]
+                if got.dtype.kind == "f":
+                    # the second Adam step is lr * m / (sqrt(v) + eps) with m, v mixing both gradients: percent-level
+                    # gradient differences show as a fraction of the step (measured: tensor means within 0.21 of it)
+                    moved = np.abs(want - weights[k].numpy()).mean()
+                    worst = max(worst, float(np.abs(got - want).mean() / (moved + 1e-12))) if moved > 1e-6 else worst
+                    assert np.abs(got - want).mean() <= 0.35 * moved + 1e-7, (k, np.abs(got - want).mean(), moved)
+                    if "running_" not in k:
+                        assert np.abs(got - want).max() <= 4.5 * lr, k
+                else:
+                    assert np.array_equal(got, want), k
+            print(f"after step 1: worst tensor-mean deviation / mean movement = {worst:.3f}")
