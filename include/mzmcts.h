@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MZMCTS_ABI_VERSION 1
+#define MZMCTS_ABI_VERSION 2
 
 /* error codes */
 #define MZMCTS_OK 0
@@ -400,7 +400,16 @@ typedef struct mzmcts_tower_layer {
     const float *const_table;  /* split tower, layer 0 with a constant last input plane: its table; else NULL */
     float *export_raw, *export_unit;
     int32_t cin, relu, skip, reserved;
+    /* layer 0 only (NULL elsewhere, and NULL = off): overflow hand-over between the two forms of a 64-channel tower,
+     * dev i32[mzmcts_board_tower_blocks(batch, channels, height, width) + 1].  The split tower WRITES it: gate[i] = 1 if a
+     * value of block i's samples left the fp16 range (|value| * 8 >= 65504) or was not finite, else 0; gate[blocks] counts
+     * flagged blocks since the caller last cleared it.  The exact-fp32 tower READS it: only blocks with gate[i] != 0 run.
+     * Launched back to back on one stream (split, then fp32 with the same layers' fp32 weights and exports) the pair
+     * re-computes overflowed samples at full range with no host in between -- also inside a captured hipGraph. */
+    int32_t *gate;
 } mzmcts_tower_layer;
+/* Blocks (workgroups of samples) a tower launch of `batch` samples has; the same for both forms of a 64-channel tower. */
+int64_t mzmcts_board_tower_blocks(int64_t batch, int32_t channels, int32_t height, int32_t width);
 int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
                        const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
 /* The same tower (channels == 64) on the 16-bit matrix path at fp32 accuracy: every operand is carried as two fp16
@@ -409,7 +418,8 @@ int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t chan
  * mzmcts_board_conv_pack_split (mzmcts_board_conv_split_halfs(cin_conv, cout) 16-bit words; cin_conv = cin - 1 when
  * const_plane).  const_plane != 0: the LAST input plane of x is one constant per sample (the dynamics input's action
  * plane, models.py:553-568); it is not convolved, its contribution comes from `const_table` (dev f32[cout, height *
- * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN). */
+ * width], written by the pack call).  |activation| must stay below 8188 (larger values turn into inf / NaN): with
+ * layers[0].gate set the launch reports the blocks where that happened, for the exact-fp32 tower to re-run. */
 int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout);
 int mzmcts_board_conv_pack_split(const float *weight, void *packed, float *const_table, int32_t cin, int32_t cout,
                                  int32_t const_plane, int32_t height, int32_t width, void *stream);

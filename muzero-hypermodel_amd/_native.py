@@ -17,7 +17,7 @@ c_f64_p = ctypes.POINTER(ctypes.c_double)
 c_f32_p = ctypes.POINTER(ctypes.c_float)
 c_void = ctypes.c_void_p
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ERR_INVALID, ERR_HIP, ERR_EMPTY_LEGAL, ERR_LEGAL_RANGE, ERR_PLAYERS = -1, -2, -3, -4, -5
 
 
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "mzmcts_board_conv_pack": (ctypes.c_int, [c_void, c_void, ctypes.c_int32, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
     "mzmcts_board_conv3x3": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void]),
+    "mzmcts_board_tower_blocks": (ctypes.c_int64, [ctypes.c_int64] + [ctypes.c_int32] * 3),
     "mzmcts_board_tower": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_split_halfs": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_board_conv_pack_split": (ctypes.c_int, [c_void, c_void, c_void] + [ctypes.c_int32] * 5 + [c_void]),
@@ -327,7 +328,8 @@ class MzTowerLayer(ctypes.Structure):
     _fields_ = [("packed", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
                 ("const_table", ctypes.c_void_p), ("export_raw", ctypes.c_void_p), ("export_unit", ctypes.c_void_p),
                 ("cin", ctypes.c_int32),
-                ("relu", ctypes.c_int32), ("skip", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("skip", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("gate", ctypes.c_void_p)]
 
 
 def exact_inverse_temperature(temperature):

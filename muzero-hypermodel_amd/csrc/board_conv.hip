@@ -286,6 +286,9 @@ constexpr int kMaxTowerLayers = 16;
 struct TowerArgs {
     TowerLayer layer[kMaxTowerLayers];
     int32_t n_layers;
+    // not null: workgroup i runs only if gate[i] != 0 -- the re-run of the blocks of samples a split-precision launch
+    // flagged as overflowed (same samples per workgroup in both kernels), queued behind it with no host in between
+    const int32_t* gate;
 };
 
 // Diagnostic build only (-DMZ_TOWER_STAMPS, tools/stamp_tower.py): cycles of wave 0 of every workgroup per phase of the
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    if (args.gate && args.gate[blockIdx.x] == 0) return;   // (uniform over the workgroup: before any barrier)
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
     const int buf1_at = SB * PP * cp0;                  // (offsets into lds, so that every access stays an LDS access)
@@ -666,6 +670,9 @@ struct SplitLayer {
 struct SplitArgs {
     SplitLayer layer[kMaxTowerLayers];
     int32_t n_layers;
+    // not null: gate[i] = 1 if a value of workgroup i's samples left the fp16 range (or was not finite), else 0, written
+    // by every launch; gate[number of workgroups] counts the flagged workgroups since it was last cleared
+    int32_t* gate;
 };
 
 template <int H, int W, int SB>
@@ -699,6 +706,10 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     constexpr int TPP = THREADS / P;
     constexpr int WALKERS = TPP * P;
 
+    // |value| * 8 must stay inside the fp16 range: anything else (inf / NaN included) flags the workgroup's samples, and
+    // the exact-fp32 tower re-runs them behind this launch (SplitArgs::gate)
+    constexpr float kHalfMax = 65504.f;
+    int overflow = 0;
     auto plane_pos = [&](int p) { return (p / W + 1) * PW + (p % W) + 1; };
     auto store_val = [&](int b, int cph, int pos, int n, float v) {       // b: the buffer's offset in hl
         const float vs = v * kActScale;
@@ -759,6 +770,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             for (int k = 0; k < 4; ++k) {
                 if (at[k] >= 0) {
                     const float vs = v[k] * kActScale;
+                    overflow |= !(__builtin_fabsf(vs) < kHalfMax);
                     const _Float16 h0 = static_cast<_Float16>(vs);
                     hl[at[k]] = h0;
                     hl[at[k] + cph0] = static_cast<_Float16>(vs - static_cast<float>(h0));
@@ -933,6 +945,11 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
                 }
                 const f32x4 vs = v * kActScale;
                 const h4 o0 = __builtin_convertvector(vs, h4);
+                {   // inf or NaN among the four high halves: an fp16 exponent field of all ones (0x7c00 + 0x0400 carries into bit 15)
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 bits = __builtin_bit_cast(u32x2, o0);
+                    overflow |= (((bits[0] & 0x7fff7fffu) + 0x04000400u) | ((bits[1] & 0x7fff7fffu) + 0x04000400u)) & 0x80008000u;
+                }
                 const h4 o1 = __builtin_convertvector(vs - __builtin_convertvector(o0, f32x4), h4);
                 *cell0 = o0;
                 *cell1 = o1;
@@ -994,6 +1011,13 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
             }
             __syncthreads();
             MZ_TSTAMP(5);
+        }
+    }
+    if (args.gate) {
+        const int any = __syncthreads_or(overflow);
+        if (tid == 0) {
+            args.gate[blockIdx.x] = any ? 1 : 0;
+            if (any) atomicAdd(&args.gate[gridDim.x], 1);
         }
     }
     MZ_TSTAMP_FLUSH;
@@ -1105,6 +1129,8 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
             return MZMCTS_ERR_INVALID;                   // (read four channels at a time)
         args.layer[l] = mz::TowerLayer{static_cast<const float*>(d.packed), d.scale, d.shift, d.export_raw, d.export_unit, d.cin, d.relu, d.skip, 0};
     }
+    args.gate = layers[0].gate;
+    if (args.gate && channels != 64) return MZMCTS_ERR_INVALID;   // (the hand-over exists between the two 64-channel forms)
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
@@ -1130,6 +1156,20 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream, gather);
     if (many) return mz::launch_board_tower<1, 3, 3, 14>(x, b, cin0, args, stream, gather);
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream, gather);
+}
+
+// samples per workgroup of the tower launches of a given shape (the table board_tower_impl / board_tower_split_impl use)
+static int tower_block_samples(int64_t batch, int32_t channels, int32_t height, int32_t width) {
+    const bool many = batch >= 16384;
+    if (height == 6 && width == 7) return channels == 64 ? 4 : 0;       // (16 channels: depends on the input's parity too)
+    if (height == 6 && width == 6) return channels == 64 ? 4 : (many ? 3 : 4);
+    return channels == 64 ? 16 : (many ? 14 : 16);
+}
+
+extern "C" int64_t mzmcts_board_tower_blocks(int64_t batch, int32_t channels, int32_t height, int32_t width) {
+    const int sb = tower_block_samples(batch, channels, height, width);
+    if (batch < 0 || sb <= 0 || !mzmcts_board_conv_supported(channels, channels, height, width)) return -1;
+    return (batch + sb - 1) / sb;
 }
 
 extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
@@ -1178,6 +1218,7 @@ static int board_tower_split_impl(const float* x, const mz::TowerGather& gather,
                                        (l == 0 && const_plane) ? d.const_table : nullptr, d.export_raw, d.export_unit,
                                        cin_conv, d.relu, d.skip, 0};
     }
+    args.gate = layers[0].gate;
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);

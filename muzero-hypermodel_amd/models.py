@@ -758,37 +758,74 @@ class MuZeroResidualNetwork(AbstractNetwork):
         # 64-channel towers run on the 16-bit matrix path with every operand split into two fp16 halves (fp32-level
         # accuracy, csrc/board_conv.hip); MZ_BOARD_CONV_PRECISION=fp32 keeps the exact-fp32 MFMA form
         split = channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
-        descs = (_native.MzTowerLayer * len(layers))()
-        keep = [x]
-        for i, (conv, bn, relu, skip) in enumerate(layers):
-            scale, shift = bn.folded()
-            table = None
-            if split:
-                packed, table = conv.packed_split(const_plane and i == 0, h, w)
-            else:
-                packed = conv.packed()
-            raw, unit = exports.get(i, (None, None))
-            keep += [scale, shift, packed, table, raw, unit]
-            descs[i] = _native.MzTowerLayer(packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                            table.data_ptr() if table is not None else None,
-                                            raw.data_ptr() if raw is not None else None,
-                                            unit.data_ptr() if unit is not None else None, conv.in_channels, relu, skip, 0)
+        # The split tower's range is |activation| < 8188; it flags the blocks of samples that left it and the exact-fp32
+        # tower, queued right behind it on the same stream, re-runs exactly those (include/mzmcts.h mzmcts_tower_layer.gate):
+        # no NaN reaches the search, no host round trip, and the pair is captured into a hipGraph like any other launch.
+        fallback = split and os.environ.get("MZ_SPLIT_FALLBACK", "on") != "off"
+        gate = self._tower_gate(b, channels, h, w, device) if fallback else None
+
+        def describe(as_split, gate_ptr):
+            descs = (_native.MzTowerLayer * len(layers))()
+            keep = []
+            for i, (conv, bn, relu, skip) in enumerate(layers):
+                scale, shift = bn.folded()
+                table = None
+                if as_split:
+                    packed, table = conv.packed_split(const_plane and i == 0, h, w)
+                else:
+                    packed = conv.packed()
+                raw, unit = exports.get(i, (None, None))
+                keep += [scale, shift, packed, table, raw, unit]
+                descs[i] = _native.MzTowerLayer(packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                table.data_ptr() if table is not None else None,
+                                                raw.data_ptr() if raw is not None else None,
+                                                unit.data_ptr() if unit is not None else None, conv.in_channels, relu, skip, 0,
+                                                gate_ptr if i == 0 else None)
+            return descs, keep
+
+        def launch(as_split, descs):
+            if gather is not None:
+                return lib.mzmcts_board_tower_gathered(ctypes.byref(gather), b, cin0, 1 if as_split else 0, channels, h, w,
+                                                       ctypes.addressof(descs), len(layers), stream)
+            if as_split:
+                return lib.mzmcts_board_tower_split(x.data_ptr(), b, cin0, 1 if const_plane else 0, channels, h, w,
+                                                    ctypes.addressof(descs), len(layers), stream)
+            return lib.mzmcts_board_tower(x.data_ptr(), b, cin0, channels, h, w, ctypes.addressof(descs), len(layers), stream)
+
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            if gather is not None:
-                rc = lib.mzmcts_board_tower_gathered(ctypes.byref(gather), b, cin0, 1 if split else 0, channels, h, w,
-                                                     ctypes.addressof(descs), len(layers), stream)
-            elif split:
-                rc = lib.mzmcts_board_tower_split(x.data_ptr(), b, cin0, 1 if const_plane else 0, channels, h, w,
-                                                  ctypes.addressof(descs), len(layers), stream)
-            else:
-                rc = lib.mzmcts_board_tower(x.data_ptr(), b, cin0, channels, h, w, ctypes.addressof(descs), len(layers),
-                                            stream)
+            descs, keep = describe(split, gate.data_ptr() if gate is not None else None)
+            rc = launch(split, descs)
+            if rc == 0 and gate is not None:
+                descs32, keep32 = describe(False, gate.data_ptr())
+                rc = launch(False, descs32)
         if rc == -1:
             return False                                 # (does not fit in LDS / shape not covered)
         if rc != 0:
             raise RuntimeError(f"mzmcts_board_tower failed ({rc}) on an input of shape {(b, cin0, h, w)}")
         return True
+
+    def _tower_gate(self, batch, channels, h, w, device):
+        """The overflow hand-over buffer of tower launches of this shape: i32[blocks + 1], same tensor for the model's
+        lifetime (a captured hipGraph keeps its address); [blocks] counts the blocks that fell back to the fp32 tower."""
+        gates = self.__dict__.setdefault("_tower_gates", {})
+        key = (int(batch), channels, h, w, str(device))
+        if key not in gates:
+            blocks = int(_native.load().mzmcts_board_tower_blocks(batch, channels, h, w))
+            if blocks <= 0:
+                raise RuntimeError(f"mzmcts_board_tower_blocks({batch}, {channels}, {h}, {w}) = {blocks}")
+            gates[key] = torch.zeros(blocks + 1, dtype=torch.int32, device=device)
+        return gates[key]
+
+    def split_tower_fallbacks(self, reset=True):
+        """Blocks of samples the split-precision towers handed to the exact-fp32 tower since the last call (their
+        activations left the fp16 range, |x| >= 8188, or were not finite).  Waits for the device."""
+        total = 0
+        for gate in self.__dict__.get("_tower_gates", {}).values():
+            total += int(gate[-1].item())
+            if reset:
+                gate[-1].zero_()
+        return total
 
     def _recurrent_tower(self, planes, out_state, gather=None, shape=None, device=None):
         """dynamics + rescale + prediction towers of recurrent_inference as one launch; None if not applicable."""

@@ -257,3 +257,55 @@ def synthetic_model(models_mod, config, device="cpu", seed=0):
     model.to(device)
     model.eval()
     return model, weights
+
+
+# ---- the value transform seen as an error amplifier (reference models.py:641-662) ----------------------
+def categorical_mean(logits, support_size):
+    """x = sum(softmax(logits) * [-s .. s]) in float64 (the quantity the inverse transform is applied to)."""
+    logits = np.asarray(logits, dtype=np.float64)
+    p = np.exp(logits - logits.max(axis=-1, keepdims=True))
+    p /= p.sum(axis=-1, keepdims=True)
+    return (p * np.arange(-support_size, support_size + 1, dtype=np.float64)).sum(axis=-1)
+
+
+def categorical_mean_bound(logit_deviation, support_size):
+    """|x' - x| for logits that differ by at most `logit_deviation` per entry: the soft-max moves by
+    ||p' - p||_1 <= 2 * ||l' - l||_inf (to first order; 1 % margin for the rest) and |x' - x| <= s * ||p' - p||_1."""
+    return 2.02 * support_size * logit_deviation
+
+
+def value_transform_bound(value, delta_x, eps=0.001):
+    """Bound on |support_to_scalar(l') - support_to_scalar(l)| for decoded value `value` (either of the two) when the
+    categorical means differ by at most delta_x, both decodes evaluated in float32 in the reference's operation order:
+
+        v = sign(x) * (z**2 - 1),   z = (sqrt(1 + 4 eps (|x| + 1 + eps)) - 1) / (2 eps)       (models.py:655-660)
+
+    * analytic part: dv/dx = 2 z / u with u = 1 + 2 eps z (= 2 at x = 0, growing like 2 sqrt(|v| + 1)): kappa * delta_x;
+    * granularity of the float32 evaluation, by forward error analysis of the seven operations (half an ulp each; the
+      soft-max and the weighted sum that produce x are charged 8 ulps).  What dominates: w = 1 + 4 eps (...) lies in
+      [1, 2) for |x| < 249, where float32 numbers are 2**-23 apart, and so does u = sqrt(w); u - 1 is exact, so
+      z = (u - 1) / (2 eps) lives on a lattice of spacing 2**-23 / (2 eps) = 6.0e-5 and v = z**2 - 1 moves in steps of
+      2 z * 6.0e-5 = 1.2e-4 * sqrt(|v| + 1).  The reference's own output cannot resolve anything finer
+      (tests/test_value_bound.py shows fixture G1 sitting on that lattice); each of the two evaluations carries this error.
+    Returns kappa(|x| + delta_x) * delta_x + 2 * (rounding error of one evaluation)."""
+    f32 = np.float32
+
+    def ulp(a):
+        return np.spacing(np.asarray(a, dtype=np.float64).astype(f32)).astype(np.float64)
+
+    value = np.abs(np.asarray(value, dtype=np.float64))
+    delta_x = np.asarray(delta_x, dtype=np.float64)
+    z = np.sqrt(value + 1.0) + delta_x                     # (z grows by at most dz/dx * delta_x <= delta_x)
+    x = z - 1.0 + eps * (z * z - 1.0)                      # the forward transform h(v), models.py:665-671
+    u = 1.0 + 2.0 * eps * z
+    kappa = 2.0 * z / u
+    e_x = 8.0 * ulp(np.maximum(x, 1.0))
+    t = x + 1.0 + eps
+    e_t = e_x + ulp(t)                                     # two additions
+    e_m = 4.0 * eps * e_t + 0.5 * ulp(4.0 * eps * t)
+    e_w = e_m + 0.5 * ulp(u * u)
+    e_u = e_w / (2.0 * u) + 0.5 * ulp(u)
+    e_z = e_u / (2.0 * eps) + 0.5 * ulp(z)                 # (u - 1 is exact)
+    e_s = 2.0 * z * e_z + 0.5 * ulp(z * z)
+    e_v = e_s + 0.5 * ulp(np.maximum(z * z - 1.0, 1e-30))
+    return 1.01 * kappa * delta_x + 2.0 * e_v

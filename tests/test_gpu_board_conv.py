@@ -196,3 +196,82 @@ def test_split_tower_single_layer_against_fp64(lib):
         err = float(((out.double().cpu() - want).abs() / magnitude).max())
         print(f"split tower layer {cin}->{cout}: max error / sum|a b| = {err:.2e}")
         assert err < 4e-7
+
+
+def test_split_tower_overflow_falls_back_to_the_fp32_tower(pkg, monkeypatch):
+    """The split-precision tower carries activations as fp16 halves scaled by 8: |x| >= 8188 does not fit.  With the
+    hand-over gate (include/mzmcts.h mzmcts_tower_layer.gate) the launch flags the blocks of samples where that happened
+    and the exact-fp32 tower behind it re-runs exactly those: the flagged samples come out as the fp32 tower computes them
+    (bit for bit -- it IS that kernel), the others as the split tower does, nothing is inf / NaN, and the count of blocks
+    that fell back is available to the host.  Without the gate the same input produces non-finite values."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.connect4").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda")
+    batch = 203                                                    # 51 blocks of 4 samples, the last one ragged
+    g = torch.Generator().manual_seed(3)
+    state = torch.rand((batch, 64, 6, 7), generator=g).cuda()
+    big = [5, 6, 77, 202]                                          # samples whose input is far outside the fp16 range / 8
+    state[big] *= 40000.0
+    action = torch.randint(0, 7, (batch, 1), generator=g).cuda()
+    outs = {}
+    with torch.no_grad():
+        planes = models.state_action_planes(state, action, 7)
+        for mode, env in (("pair", {}), ("fp32", {"MZ_BOARD_CONV_PRECISION": "fp32"}), ("split_only", {"MZ_SPLIT_FALLBACK": "off"})):
+            for k in ("MZ_BOARD_CONV_PRECISION", "MZ_SPLIT_FALLBACK"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            if mode == "pair":
+                model.split_tower_fallbacks()                      # (clears the counters)
+            raw, unit, features = model._recurrent_tower(planes, None)
+            outs[mode] = [t.clone() for t in (raw, unit, features)]
+            if mode == "pair":
+                fell_back = model.split_tower_fallbacks()
+    blocks = sorted({s // 4 for s in big})
+    assert fell_back == len(blocks)
+    flagged = torch.zeros(batch, dtype=torch.bool)
+    for blk in blocks:
+        flagged[blk * 4: blk * 4 + 4] = True
+    for got, exact, alone, what in zip(outs["pair"], outs["fp32"], outs["split_only"], ("raw", "unit", "features")):
+        assert torch.isfinite(got).all(), what
+        assert torch.equal(got[flagged], exact[flagged]), what      # re-run by the exact-fp32 kernel
+        assert torch.equal(got[~flagged], alone[~flagged]), what    # untouched split results
+        assert not torch.isfinite(alone[big]).all(), what           # (what the split tower alone makes of them)
+
+
+def test_search_with_overflowing_activations_runs_on_the_fallback(pkg, monkeypatch):
+    """A Connect4 network whose dynamics activations leave the split tower's range (batch-norm gains scaled up: what a
+    trained network may do mid-run) searches without a NaN: every simulation's tower pair falls back, hipGraph-captured
+    loop included, and the search equals the one run on the exact-fp32 towers from the start."""
+    import numpy as np
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    eng = importlib.import_module("muzero-hypermodel_amd.engine")
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.connect4").MuZeroConfig()
+    config.num_simulations = 30
+    _, weights = synthetic_model(models, config, "cpu")
+    weights = {k: v.clone() for k, v in weights.items()}
+    weights["dynamics_network.module.bn.weight"] *= 3.0e4           # first dynamics layer: activations ~1e4 .. 1e5
+    E = 16
+    rs = np.random.RandomState(1)
+    obs = rs.randint(-1, 2, (E, 3, 6, 7)).astype(np.float32)
+    results = {}
+    for mode in ("split", "fp32"):
+        monkeypatch.setenv("MZ_BOARD_CONV_PRECISION", mode)
+        model = models.MuZeroNetwork(config)
+        model.set_weights(weights)
+        model.cuda().eval()
+        engine = eng.BatchedMCTS(config, E, seeds=list(range(E)), use_graph=True)
+        out = []
+        for _ in range(3):                                          # eager, capturing, replay
+            st = engine.search(model, obs, [list(range(7))] * E, [0] * E, True)
+            out.append((st["visits"].copy(), st["root_value_sum"].copy()))
+        results[mode] = out
+        if mode == "split":
+            assert engine._graph is not None
+            assert model.split_tower_fallbacks() >= 3 * config.num_simulations        # every launch handed blocks over
+        engine.close()
+    for (v_a, r_a), (v_b, r_b) in zip(results["split"], results["fp32"]):
+        assert np.isfinite(r_a).all()
+        assert np.array_equal(v_a, v_b) and np.array_equal(r_a, r_b)

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(lib, name), f"{name} declared in include/mzmcts.h but not exported"
     # and the Python binding covers exactly the header
     assert sorted(native.PROTOTYPES) == names
-    assert lib.mzmcts_abi_version() == 1
+    assert lib.mzmcts_abi_version() == native.ABI_VERSION == 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
