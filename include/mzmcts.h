@@ -312,6 +312,28 @@ int mzmcts_moves_prepare_device(mzmcts_engine *engine, int32_t n_moves, const in
                                 const double *temperature, void *stream);
 int mzmcts_moves_inputs(mzmcts_engine *engine, int32_t *num_legal, int32_t *legal_actions, int32_t *to_play);
 int mzmcts_moves_enqueue(mzmcts_engine *engine, const float *observations, void *stream);
+/* A move of a device-input batch searched LOCK-STEP -- any network, the caller runs it between the tree launches -- with
+ * no host round trip (self_play.py:129-182 for every env, queued on one stream):
+ *   mzmcts_moves_begin_lockstep   records the move's inputs for the host, copies them into the engine's own root inputs,
+ *                                 steps over the mirrors' pending RNG words, draws the exploration noise on the device;
+ *                                 the engine is then where mzmcts_begin_search leaves it
+ *   ... mzmcts_expand_roots, S x (mzmcts_select* / the network / mzmcts_expand_backup) -- or the replay of a hipGraph that
+ *       holds them ...
+ *   mzmcts_moves_end_lockstep     SelfPlay.select_action (self_play.py:223-246) on each tree's own stream from the root's
+ *                                 visit counts, the move's slot of the output ring (mzmcts_moves_actions(move) is what
+ *                                 the environment kernels step with), and the batch moves on to its next move
+ * mzmcts_moves_collect afterwards as for any batch.  Needs no fully-connected network (mzmcts_moves_enqueue does). */
+int mzmcts_moves_begin_lockstep(mzmcts_engine *engine, void *stream);
+int mzmcts_moves_end_lockstep(mzmcts_engine *engine, void *stream);
+/* play_game's temperature rule inside a device-input batch (self_play.py:152-158: the given temperature only while
+ * len(game_history.action_history) < temperature_threshold, the best action afterwards).  Call right after
+ * mzmcts_moves_prepare_device: game_moves host i32[E] = moves already played in each env's current game; the kernels keep
+ * the counters from there (every searched move adds one).  threshold 0 = no rule.
+ * mzmcts_moves_finished: dev u8[E], the environment kernels' `done` flags of the move just played (mzenv_advance's
+ * done_out) -- envs flagged there start a new game, their counter restarts at the next move of the batch.  One-shot:
+ * consumed by the next mzmcts_moves_enqueue / mzmcts_moves_begin_lockstep. */
+int mzmcts_moves_temperature_threshold(mzmcts_engine *engine, int32_t threshold, const int32_t *game_moves, void *stream);
+int mzmcts_moves_finished(mzmcts_engine *engine, const uint8_t *finished);
 const int32_t *mzmcts_moves_actions(mzmcts_engine *engine, int32_t move);
 int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *actions, int32_t *visits,
                          double *root_value_sum, float *root_predicted, int32_t *max_depth, void *stream);

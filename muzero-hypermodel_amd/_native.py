@@ -114,6 +114,10 @@ PROTOTYPES = {
     "mzmcts_moves_prepare_device": (ctypes.c_int, [c_void, ctypes.c_int32, c_void, c_void, c_void, ctypes.c_int32, c_f64_p, c_void]),
     "mzmcts_moves_inputs": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p]),
     "mzmcts_moves_enqueue": (ctypes.c_int, [c_void, c_void, c_void]),
+    "mzmcts_moves_begin_lockstep": (ctypes.c_int, [c_void, c_void]),
+    "mzmcts_moves_end_lockstep": (ctypes.c_int, [c_void, c_void]),
+    "mzmcts_moves_temperature_threshold": (ctypes.c_int, [c_void, ctypes.c_int32, c_i32_p, c_void]),
+    "mzmcts_moves_finished": (ctypes.c_int, [c_void, c_void]),
     "mzmcts_moves_actions": (c_void, [c_void, ctypes.c_int32]),
     "mzmcts_moves_ring": (ctypes.c_int, [c_void, ctypes.POINTER(c_void), c_i64_p, c_i64_p, c_i32_p]),
     "mzmcts_moves_collect": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_f64_p, c_f32_p, c_i32_p, c_void]),

@@ -56,7 +56,8 @@ hipError_t launch_select(const TreeParams& p, int sim, float* hidden_out, int64_
 hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_t stream);
 hipError_t launch_move_inputs(const TreeParams& p, const uint32_t* rng_skip, const uint8_t* stall, const int32_t* move_limit,
                               int move_index, bool draw_noise, int32_t* nlegal_out, int32_t* to_play_out, uint32_t* words_out,
-                              int32_t* legal_out, hipStream_t stream);
+                              int32_t* legal_out, const MoveInputsExtra& extra, hipStream_t stream);
+hipError_t launch_lockstep_move_finish(const TreeParams& p, const MoveCtl& ctl, hipStream_t stream);
 hipError_t launch_gather_dynamics_input(const TreeParams& p, const int64_t* action, float* out, int plane, int action_space,
                                         hipStream_t stream);
 hipError_t launch_expand_roots(const TreeParams& p, const float* value_logits, const float* reward_logits,
@@ -317,7 +318,15 @@ struct mzmcts_engine {
         int inputs_capacity = 0;
         size_t in2_stride = 0, o2_nlegal = 0, o2_to_play = 0, o2_words = 0, o2_legal = 0;
         uint8_t *d_inputs = nullptr, *h_inputs = nullptr;   // [M] blocks: nlegal i32[E] | to_play i32[E] | noise words u32[E] | legal i32[E][A]
+        // play_game's temperature threshold inside a batch (MoveCtl::game_moves): moves of each env's current game, kept
+        // on the device over the batch; `finished` = the env kernels' done flags of the move before (one-shot)
+        int32_t temperature_threshold = 0;
+        uint8_t* d_game_moves = nullptr;             // i32[E]
+        const uint8_t* finished = nullptr;
+        bool lockstep_open = false;                  // between mzmcts_moves_begin_lockstep and mzmcts_moves_end_lockstep
     } batch;
+    int32_t *own_root_action = nullptr, *own_root_children = nullptr, *own_root_to_play = nullptr;   // (scratch of move_extras)
+    bool skip_applied = false;   // the search in progress had its pending words stepped over already (lock-step batch moves)
 
     // pending asynchronous readout (mzmcts_readout_begin)
     hipEvent_t readout_event = nullptr;

@@ -237,9 +237,10 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         uint32_t sample_words = 0;
         if (ctl.temperature) {  // SelfPlay.select_action on the tree's own stream (kernel_common.h)
             const ChildLinks* root_links = tree.links(0);
-            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, ctl.temperature[e],
+            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, move_temperature(ctl, e),
                                                   mt_key, &mt_pos, &sample_words);
             if (ctl.actions) ctl.actions[e] = slot >= 0 ? root_action_lds[slot] : slot;
+            if (ctl.game_moves) ctl.game_moves[e] += 1;        // this env's game is one move longer
         }
         if (words | sample_words) p.mt_pos[e] = mt_pos;
         if (words) p.tie_words[e] = words;

@@ -79,6 +79,27 @@ struct MoveCtl {
     uint32_t* tie_words;          // [E] RNG words the search consumed (tie-breaks)
     uint32_t* sample_words;       // [E] RNG words the action sampling consumed
     int32_t* depth_sum;           // [E] sum of the S descent depths
+    // play_game's temperature rule (self_play.py:152-158): temperature only while len(action_history) < threshold, i.e.
+    // while fewer than threshold - 1 moves of the env's current game were played; afterwards the best action (T = 0)
+    int32_t* game_moves;          // [E] moves played in env e's current game (the kernel counts its own move); null = no rule
+    int32_t temperature_threshold; // 0 = none
+};
+
+// The temperature select_action is called with for env e's move (see MoveCtl::game_moves).
+__device__ __forceinline__ double move_temperature(const MoveCtl& ctl, int e) {
+    const double t = ctl.temperature[e];
+    if (ctl.game_moves && ctl.temperature_threshold > 0 && ctl.game_moves[e] + 1 >= ctl.temperature_threshold) return 0.0;
+    return t;
+}
+
+// Optional extras of move_inputs_kernel (mcts_kernels.hip): a second copy of the root inputs into the engine's own arrays
+// (lock-step moves) and the per-game move counters of the temperature-threshold rule.
+struct MoveInputsExtra {
+    int32_t* own_legal = nullptr;       // [E][A]
+    int32_t* own_nlegal = nullptr;      // [E]
+    int32_t* own_to_play = nullptr;     // [E]
+    int32_t* game_moves = nullptr;      // [E]
+    const uint8_t* finished = nullptr;  // [E] the env kernels' `done` of the move before, or null
 };
 
 // Group-uniform: true = this env must not be searched in this move (see MoveCtl).

@@ -592,13 +592,20 @@ __global__ __launch_bounds__(kThreads) void move_inputs_kernel(TreeParams p, con
                                                                int draw_noise, int32_t* __restrict__ nlegal_out,
                                                                int32_t* __restrict__ to_play_out,
                                                                uint32_t* __restrict__ words_out,
-                                                               int32_t* __restrict__ legal_out) {
+                                                               int32_t* __restrict__ legal_out, MoveInputsExtra extra) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.E) return;
     const int n = p.root_children[e];
     nlegal_out[e] = n;
     to_play_out[e] = p.root_to_play[e];
     for (int i = 0; i < p.A; ++i) legal_out[static_cast<size_t>(e) * p.A + i] = p.root_action[static_cast<size_t>(e) * p.A + i];
+    if (extra.own_nlegal) {   // lock-step moves: the engine's own root inputs (what its captured simulation loop reads)
+        extra.own_nlegal[e] = n;
+        extra.own_to_play[e] = p.root_to_play[e];
+        for (int i = 0; i < p.A; ++i) extra.own_legal[static_cast<size_t>(e) * p.A + i] = p.root_action[static_cast<size_t>(e) * p.A + i];
+    }
+    // an env whose game ended with the move before starts a new one: its move counter restarts (MoveCtl::game_moves)
+    if (extra.game_moves && extra.finished && extra.finished[e]) extra.game_moves[e] = 0;
     words_out[e] = 0u;
     double* row = p.noise_rows + static_cast<size_t>(e) * p.A;
     for (int i = 0; i < p.A; ++i) row[i] = 0.0;
@@ -842,9 +849,10 @@ __global__ __launch_bounds__(kThreads) void search_fused_fc_kernel(TreeParams p,
         uint32_t sample_words = 0;
         if (ctl.temperature) {  // SelfPlay.select_action on the tree's own stream (kernel_common.h)
             const ChildLinks* root_links = tree.links(0);
-            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, ctl.temperature[e],
+            const int slot = device_select_action([&](int i) { return root_links[i].visits; }, n_root, move_temperature(ctl, e),
                                                   mt_key, &mt_pos, &sample_words);
             if (ctl.actions) ctl.actions[e] = slot >= 0 ? p.root_action[static_cast<size_t>(e) * p.A + slot] : slot;
+            if (ctl.game_moves) ctl.game_moves[e] += 1;        // this env's game is one move longer
         }
         if (words | sample_words) p.mt_pos[e] = mt_pos;
         if (words) p.tie_words[e] = words;
@@ -973,9 +981,43 @@ hipError_t launch_root_noise(const TreeParams& p, uint32_t* rng_skip, hipStream_
 
 hipError_t launch_move_inputs(const TreeParams& p, const uint32_t* rng_skip, const uint8_t* stall, const int32_t* move_limit,
                               int move_index, bool draw_noise, int32_t* nlegal_out, int32_t* to_play_out, uint32_t* words_out,
-                              int32_t* legal_out, hipStream_t stream) {
+                              int32_t* legal_out, const MoveInputsExtra& extra, hipStream_t stream) {
     move_inputs_kernel<<<dim3((p.E + kThreads - 1) / kThreads), dim3(kThreads), 0, stream>>>(
-        p, rng_skip, stall, move_limit, move_index, draw_noise ? 1 : 0, nlegal_out, to_play_out, words_out, legal_out);
+        p, rng_skip, stall, move_limit, move_index, draw_noise ? 1 : 0, nlegal_out, to_play_out, words_out, legal_out, extra);
+    return hipGetLastError();
+}
+
+// The end of a lock-step move of a batch (mzmcts_moves_end_lockstep): what the fused whole-move kernels do in their
+// epilogue -- SelfPlay.select_action (self_play.py:223-246) on the tree's own stream from the root's visit counts, and the
+// move's slot of the output ring -- for trees that live in the HBM pools.  One thread per tree: a few dozen operations.
+__global__ __launch_bounds__(kThreads) void lockstep_move_finish_kernel(TreeParams p, MoveCtl ctl) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.E) return;
+    const int n = p.root_children[e];
+    const HbmChild* root = reinterpret_cast<const HbmChild*>(p.blocks + static_cast<size_t>(e) * p.line_stride);   // line (0, e), half 0
+    if (ctl.visits)
+        for (int i = 0; i < p.A; ++i) ctl.visits[static_cast<size_t>(e) * p.A + i] = (i < n) ? root[i].links.visits : 0;
+    if (n == 0) {
+        if (ctl.actions) ctl.actions[e] = -1;
+        return;
+    }
+    uint32_t sample_words = 0;
+    int32_t pos = p.mt_pos[e];
+    const int slot = device_select_action([&](int i) { return root[i].links.visits; }, n, move_temperature(ctl, e),
+                                          p.mt_key + static_cast<size_t>(e) * kMtN, &pos, &sample_words);
+    if (sample_words) p.mt_pos[e] = pos;
+    if (ctl.actions) ctl.actions[e] = slot >= 0 ? p.root_action[static_cast<size_t>(e) * p.A + slot] : slot;
+    if (ctl.game_moves) ctl.game_moves[e] += 1;
+    if (ctl.tie_words) ctl.tie_words[e] = p.tie_words[e];
+    if (ctl.sample_words) ctl.sample_words[e] = sample_words;
+    if (ctl.root_value_sum) ctl.root_value_sum[e] = p.root_value_sum[e];
+    if (ctl.root_predicted) ctl.root_predicted[e] = p.root_predicted[e];
+    if (ctl.max_depth) ctl.max_depth[e] = p.max_depth[e];
+    if (ctl.depth_sum) ctl.depth_sum[e] = static_cast<int32_t>(p.depth_sum[e]);
+}
+
+hipError_t launch_lockstep_move_finish(const TreeParams& p, const MoveCtl& ctl, hipStream_t stream) {
+    lockstep_move_finish_kernel<<<dim3((p.E + kThreads - 1) / kThreads), dim3(kThreads), 0, stream>>>(p, ctl);
     return hipGetLastError();
 }
 

@@ -301,6 +301,7 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
         std::fprintf(stderr, "[mzmcts] begin_search E=%d: host prep+dirichlet %.1f us, memcpy+enqueue %.1f us\n", E,
                      t_dirichlet - t_start, now() - t_dirichlet);
     eng->search_begun = true;
+    eng->skip_applied = false;
     eng->tie_words_applied = false;
     eng->roots_ready = false;
     eng->have_readout = false;
@@ -315,8 +316,8 @@ static int expand_roots_common(mzmcts_engine* eng, const float* value_logits, co
     {
         ProfScope scope(eng, stream, kProfRoot);
         MZ_HIP(eng, mz::launch_expand_roots(eng->p, value_logits, reward_logits, policy_logits, root_hidden, inj_reward,
-                                            inj_priors, eng->noise_this_search ? eng->d_noise : nullptr, eng->d_skip,
-                                            injected, stream, scope.get()));
+                                            inj_priors, eng->noise_this_search ? eng->d_noise : nullptr,
+                                            eng->skip_applied ? nullptr : eng->d_skip, injected, stream, scope.get()));
     }
     eng->roots_ready = true;
     eng->tree_published = true;

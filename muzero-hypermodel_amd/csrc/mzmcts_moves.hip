@@ -47,6 +47,8 @@ static void restore_stream(mzmcts_engine* eng, int e, const MoveRecord& target, 
     s.gauss = target.gauss;
 }
 
+static mz::MoveInputsExtra move_extras(mzmcts_engine* eng, bool own_inputs);
+
 static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
     mzmcts_engine::MoveBatch& b = eng->batch;
     if (n_moves <= b.capacity) return 0;
@@ -270,7 +272,7 @@ int mzmcts_moves_prepare_device(mzmcts_engine* eng, int32_t n_moves, const int32
                                 const int32_t* to_play_dev, int32_t add_noise, const double* temperature, void* stream_) {
     if (!eng || !legal_dev || !num_legal_dev || !to_play_dev || !temperature)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: null argument");
-    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: call mzmcts_fc_configure first");
+    // (a fully-connected network is needed by mzmcts_moves_enqueue only: lock-step moves bring their own network)
     if (n_moves < 1 || n_moves > 4096) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: n_moves out of range");
     if (add_noise && !(eng->cfg.root_dirichlet_alpha > 0.0 && eng->cfg.root_dirichlet_alpha <= 1.0))
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_prepare_device: the device draws Dirichlet noise for 0 < "
@@ -309,6 +311,9 @@ int mzmcts_moves_prepare_device(mzmcts_engine* eng, int32_t n_moves, const int32
     b.enqueued = 0;
     b.in_flight = true;
     b.device_inputs = true;
+    b.temperature_threshold = 0;                     // (mzmcts_moves_temperature_threshold sets it per batch)
+    b.finished = nullptr;
+    b.lockstep_open = false;
     b.dev_legal = legal_dev;
     b.dev_nlegal = num_legal_dev;
     b.dev_to_play = to_play_dev;
@@ -393,6 +398,8 @@ int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* st
     const ChainSet& c = b.set[b.cur];
     if (!b.in_flight || b.enqueued >= c.n_moves)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: no prepared move left in the batch");
+    if (!eng->fc_ready) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: call mzmcts_fc_configure first");
+    if (b.lockstep_open) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_enqueue: a lock-step move is open (mzmcts_moves_end_lockstep)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t E = static_cast<size_t>(eng->p.E), A = static_cast<size_t>(eng->p.A);
     const int m = b.enqueued;
@@ -412,7 +419,8 @@ int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* st
                                                 c.add_noise, reinterpret_cast<int32_t*>(blk + b.o2_nlegal),
                                                 reinterpret_cast<int32_t*>(blk + b.o2_to_play),
                                                 reinterpret_cast<uint32_t*>(blk + b.o2_words),
-                                                reinterpret_cast<int32_t*>(blk + b.o2_legal), stream);
+                                                reinterpret_cast<int32_t*>(blk + b.o2_legal), move_extras(eng, false), stream);
+        b.finished = nullptr;
         if (err != hipSuccess) {
             eng->p.root_action = const_cast<int32_t*>(host_legal), eng->p.root_children = const_cast<int32_t*>(host_nlegal);
             eng->p.root_to_play = const_cast<int32_t*>(host_to_play);
@@ -434,12 +442,132 @@ int mzmcts_moves_enqueue(mzmcts_engine* eng, const float* observations, void* st
     ctl.tie_words = reinterpret_cast<uint32_t*>(out + b.o_ties);
     ctl.sample_words = reinterpret_cast<uint32_t*>(out + b.o_sample);
     ctl.depth_sum = reinterpret_cast<int32_t*>(out + b.o_dsum);
+    if (b.device_inputs && b.temperature_threshold > 0) {
+        ctl.game_moves = reinterpret_cast<int32_t*>(b.d_game_moves);
+        ctl.temperature_threshold = b.temperature_threshold;
+    }
     int rc = mzhost_launch_fused_move(eng, observations, ctl, true, stream);
     eng->p.root_action = const_cast<int32_t*>(host_legal);
     eng->p.root_children = const_cast<int32_t*>(host_nlegal);
     eng->p.root_to_play = const_cast<int32_t*>(host_to_play);
     if (rc) return rc;
     b.enqueued = m + 1;
+    return MZMCTS_OK;
+}
+
+int mzmcts_moves_temperature_threshold(mzmcts_engine* eng, int32_t threshold, const int32_t* game_moves, void* stream_) {
+    if (!eng || threshold < 0 || (threshold > 0 && !game_moves))
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_temperature_threshold: bad argument");
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.in_flight || !b.device_inputs || b.enqueued != 0)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_temperature_threshold: call right after mzmcts_moves_prepare_device");
+    b.temperature_threshold = threshold;
+    if (threshold == 0) return MZMCTS_OK;
+    const size_t bytes = sizeof(int32_t) * static_cast<size_t>(eng->p.E);
+    int rc;
+    if (!b.d_game_moves && (rc = dev_alloc(eng, &b.d_game_moves, bytes))) return rc;
+    // (pageable source: the copy is staged before the call returns, the caller's array may go)
+    MZ_HIP(eng, hipMemcpyAsync(b.d_game_moves, game_moves, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream_)));
+    return MZMCTS_OK;
+}
+
+int mzmcts_moves_finished(mzmcts_engine* eng, const uint8_t* finished_dev) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.in_flight || !b.device_inputs)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_finished: no device-input batch in flight");
+    b.finished = finished_dev;
+    return MZMCTS_OK;
+}
+
+// what move_inputs_kernel does beyond recording the inputs for the host (see MoveInputsExtra)
+static mz::MoveInputsExtra move_extras(mzmcts_engine* eng, bool own_inputs) {
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    mz::MoveInputsExtra x{};
+    if (own_inputs) {
+        x.own_legal = eng->own_root_action;
+        x.own_nlegal = eng->own_root_children;
+        x.own_to_play = eng->own_root_to_play;
+    }
+    if (b.temperature_threshold > 0) {
+        x.game_moves = reinterpret_cast<int32_t*>(b.d_game_moves);
+        x.finished = b.finished;
+    }
+    return x;
+}
+
+// ---- a move of a device-input batch searched lock-step (the caller runs the network between the tree launches) --------
+int mzmcts_moves_begin_lockstep(mzmcts_engine* eng, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    const ChainSet& c = b.set[b.cur];
+    if (!b.in_flight || !b.device_inputs || b.enqueued >= c.n_moves)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_begin_lockstep: no prepared move left in a device-input batch");
+    if (b.lockstep_open) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_begin_lockstep: the move before is still open");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int m = b.enqueued;
+    const size_t E = static_cast<size_t>(eng->p.E);
+    // the kernel reads the caller's device arrays (the env kernels' outputs), records them for the host, copies them
+    // into the engine's own root inputs -- which every later launch of the move reads, a replayed hipGraph included --,
+    // steps over the mirrors' pending words and draws the noise row on the device
+    mz::TreeParams view = eng->p;
+    view.root_action = const_cast<int32_t*>(b.dev_legal);
+    view.root_children = const_cast<int32_t*>(b.dev_nlegal);
+    view.root_to_play = const_cast<int32_t*>(b.dev_to_play);
+    uint8_t* blk = b.d_inputs + b.in2_stride * static_cast<size_t>(m);
+    eng->own_root_action = eng->p.root_action;
+    eng->own_root_children = eng->p.root_children;
+    eng->own_root_to_play = eng->p.root_to_play;
+    hipError_t err = mz::launch_move_inputs(view, reinterpret_cast<const uint32_t*>(b.d_in + b.o_skip) + static_cast<size_t>(m) * E,
+                                            b.d_stall, reinterpret_cast<const int32_t*>(b.d_in + b.o_limit), m, c.add_noise,
+                                            reinterpret_cast<int32_t*>(blk + b.o2_nlegal), reinterpret_cast<int32_t*>(blk + b.o2_to_play),
+                                            reinterpret_cast<uint32_t*>(blk + b.o2_words), reinterpret_cast<int32_t*>(blk + b.o2_legal),
+                                            move_extras(eng, true), stream);
+    b.finished = nullptr;
+    if (err != hipSuccess) return hip_fail(eng, err, "move_inputs_kernel");
+    b.lockstep_open = true;
+    eng->noise_this_search = c.add_noise;
+    eng->noise_on_device = false;        // (the batch's collect() accounts for the words: readout is not used)
+    eng->skip_applied = true;
+    eng->search_begun = true;
+    eng->tie_words_applied = true;
+    eng->roots_ready = false;
+    eng->have_readout = false;
+    eng->sim = 0;
+    return MZMCTS_OK;
+}
+
+int mzmcts_moves_end_lockstep(mzmcts_engine* eng, void* stream_) {
+    if (!eng) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.lockstep_open) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_end_lockstep: no lock-step move is open");
+    if (!eng->roots_ready || eng->sim != eng->p.S)
+        return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_end_lockstep: expand_roots and all simulations must have run");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int m = b.enqueued;
+    uint8_t* out = b.d_out + b.out_stride * static_cast<size_t>(m);
+    mz::MoveCtl ctl{};
+    ctl.temperature = reinterpret_cast<const double*>(b.d_in + b.o_temp);
+    ctl.move_index = m;
+    ctl.actions = reinterpret_cast<int32_t*>(out + b.o_actions);
+    ctl.visits = reinterpret_cast<int32_t*>(out + b.o_visits);
+    ctl.root_value_sum = reinterpret_cast<double*>(out + b.o_rvs);
+    ctl.root_predicted = reinterpret_cast<float*>(out + b.o_pred);
+    ctl.max_depth = reinterpret_cast<int32_t*>(out + b.o_depth);
+    ctl.tie_words = reinterpret_cast<uint32_t*>(out + b.o_ties);
+    ctl.sample_words = reinterpret_cast<uint32_t*>(out + b.o_sample);
+    ctl.depth_sum = reinterpret_cast<int32_t*>(out + b.o_dsum);
+    if (b.temperature_threshold > 0) {
+        ctl.game_moves = reinterpret_cast<int32_t*>(b.d_game_moves);
+        ctl.temperature_threshold = b.temperature_threshold;
+    }
+    hipError_t err = mz::launch_lockstep_move_finish(eng->p, ctl, stream);
+    if (err != hipSuccess) return hip_fail(eng, err, "lockstep_move_finish_kernel");
+    b.lockstep_open = false;
+    b.enqueued = m + 1;
+    eng->search_begun = false;
+    eng->roots_ready = false;
+    eng->skip_applied = false;
     return MZMCTS_OK;
 }
 

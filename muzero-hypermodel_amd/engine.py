@@ -69,7 +69,7 @@ class BatchedMCTS:
         self.stream = None          # optional dedicated torch.cuda.Stream (PipelinedSearch)
         self._fc_model = None
         self._ring_moves = ctypes.c_int32()
-        self._batch_keep = []
+        self._batch_keep, self._batch_moves = [], 0
         self._fc_flat = None
         self.fused_hidden_in_lds = True
         # lock-step loop: expand_backup + next select in one launch (mzmcts_expand_backup_select).  Bit-identical and one
@@ -527,7 +527,7 @@ class BatchedMCTS:
         t = self._move_inputs(legal_actions, to_play, temperature, num_legal)
         self._check(self._lib.mzmcts_moves_prepare(self._h, int(n_moves), self._p_legal, self._p_nlegal, self._p_to_play,
                                                    1 if add_exploration_noise else 0, ptr(t, c_f64_p), self._stream()))
-        self._batch_keep = []
+        self._batch_keep, self._batch_moves = [], 0
         self._moves_ring()
 
     def moves_predraw_next(self, n_moves, legal_actions, to_play, temperature, add_exploration_noise=True,
@@ -541,7 +541,7 @@ class BatchedMCTS:
     def moves_submit_next(self):
         """After moves_collect: upload the pre-drawn batch; moves_enqueue may follow."""
         self._check(self._lib.mzmcts_moves_submit_next(self._h, self._stream()))
-        self._batch_keep = []
+        self._batch_keep, self._batch_moves = [], 0
 
     def moves_discard_next(self):
         """Drop a pre-drawn batch that will not be run (the RNG mirror goes back)."""
@@ -554,7 +554,7 @@ class BatchedMCTS:
         for t, shape in ((legal_dev, (self.E, self.A)), (num_legal_dev, (self.E,)), (to_play_dev, (self.E,))):
             assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == shape
         temps = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, dtype=np.float64), (self.E,)))
-        self._batch_keep = []
+        self._batch_keep, self._batch_moves = [], 0
         self._batch_inputs_keep = (legal_dev, num_legal_dev, to_play_dev)
         self._check(self._lib.mzmcts_moves_prepare_device(self._h, int(n_moves), legal_dev.data_ptr(), num_legal_dev.data_ptr(),
                                                           to_play_dev.data_ptr(), 1 if add_exploration_noise else 0,
@@ -574,7 +574,42 @@ class BatchedMCTS:
         assert observations.is_cuda and observations.dtype == torch.float32 and observations.is_contiguous()
         assert observations.numel() == self.E * self._fc_obs_floats, "observation batch has the wrong size"
         self._batch_keep.append(observations)
+        self._batch_moves += 1
         self._check(self._lib.mzmcts_moves_enqueue(self._h, observations.data_ptr(), self._stream()))
+
+    @torch.no_grad()
+    def moves_enqueue_lockstep(self, model, observations):
+        """Queue the next move of a device-input batch (moves_prepare_device) searched LOCK-STEP with `model` -- any
+        network: root inference, root expansion with device-drawn noise, the S simulations (the captured hipGraph once
+        there is one) and the action sampling on the device, all on the current stream, no host round trip.
+        `observations`: resident fp32 CUDA tensor [E, C, H, W] (the environment kernels' output)."""
+        if not (torch.is_tensor(observations) and observations.is_cuda and observations.dtype == torch.float32):
+            raise TypeError("moves_enqueue_lockstep: observations must be a resident fp32 CUDA tensor")
+        with torch.cuda.device(self.device):
+            value, reward, policy, hidden = model.initial_inference(observations)
+            self._check(self._lib.mzmcts_moves_begin_lockstep(self._h, self._stream()))
+            self.expand_roots(value, reward.contiguous(), policy, hidden)
+            self._run_simulations(model)
+            self._check(self._lib.mzmcts_moves_end_lockstep(self._h, self._stream()))
+        self._batch_keep.append(observations)
+        self._batch_moves += 1
+
+    def moves_temperature_threshold(self, threshold, game_moves):
+        """play_game's temperature rule for the batch just prepared with moves_prepare_device (reference
+        self_play.py:152-158): `game_moves` [E] = moves already played in each env's current game."""
+        counts = np.ascontiguousarray(game_moves, dtype=np.int32)
+        assert counts.shape == (self.E,)
+        self._check(self._lib.mzmcts_moves_temperature_threshold(self._h, int(threshold or 0), ptr(counts, c_i32_p),
+                                                                 self._stream()))
+        if threshold:
+            torch.cuda.current_stream(self.device).synchronize()    # (the upload reads `counts`)
+
+    def moves_finished(self, done_dev):
+        """The environment kernels' done flags (uint8 [E], device) of the move just played: envs flagged there start a
+        new game at the batch's next move (their move counter restarts)."""
+        assert done_dev.is_cuda and done_dev.dtype == torch.uint8 and done_dev.is_contiguous() and done_dev.numel() == self.E
+        self._batch_keep.append(done_dev)
+        self._check(self._lib.mzmcts_moves_finished(self._h, done_dev.data_ptr()))
 
     def moves_actions(self, move):
         """Device tensor (int32 [E]) holding move `move`'s sampled actions once its search has run."""
@@ -601,7 +636,7 @@ class BatchedMCTS:
         root_value_sum [M,E], root_predicted [M,E], max_depth [M,E]); M = searches queued.
         copy=False: the per-move arrays are views of the library's pinned download ring (no unpacking pass):
         valid until the next moves_collect, and an env's entries in moves >= moves_done[e] are undefined."""
-        M = len(self._batch_keep)
+        M = self._batch_moves
         out = dict(moves_done=np.zeros(self.E, np.int32))
         if copy:
             out.update(actions=np.zeros((M, self.E), np.int32), visits=np.zeros((M, self.E, self.A), np.int32),
@@ -625,7 +660,7 @@ class BatchedMCTS:
             out.update(actions=view(offsets[0], np.int32, (self.E,)), visits=view(offsets[1], np.int32, (self.E, self.A)),
                        root_value_sum=view(offsets[2], np.float64, (self.E,)),
                        root_predicted=view(offsets[3], np.float32, (self.E,)), max_depth=view(offsets[4], np.int32, (self.E,)))
-        self._batch_keep = []
+        self._batch_keep, self._batch_moves = [], 0
         return out
 
     def run_moves(self, observations, legal_actions, to_play, temperature, add_exploration_noise=True, num_legal=None):

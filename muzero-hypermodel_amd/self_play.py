@@ -951,22 +951,25 @@ class DeviceSelfPlay(ManyEnvLoop):
             self._tp[idx, 0] = to_play_next[idx]
 
     # ---- whole batches of moves on the device (engine.moves_*, include/mzmcts.h) ---------------------------
-    def play_moves(self, n_moves, temperature, on_game=None, on_games=None):
+    def play_moves(self, n_moves, temperature, on_game=None, on_games=None, temperature_threshold=None):
         """`n_moves` moves of every env with no host round trip in between: search (which samples the action),
-        env step, terminal observation, reset of finished envs, next observation -- all queued on one stream;
-        the exploration noise of the whole batch is drawn up front (and the next batch's while this one runs).
-        Needs a fully-connected network.  Games whose legal action set changes (board games) take the device-input
-        form of the batch (_play_moves_device_inputs).
+        env step, terminal observation, reset of finished envs, next observation -- all queued on one stream.
+        Fully-connected networks search in the fused whole-move kernel (games with a constant legal set: the exploration
+        noise of the whole batch is drawn up front, and the next batch's while this one runs); residual networks search
+        lock-step (engine.moves_enqueue_lockstep) with inputs, noise and action sampling on the device.
+        `temperature_threshold` (default config.temperature_threshold) is play_game's rule, applied per env and move.
         An env may come back with fewer than n_moves moves played (it plays the rest next time)."""
         E, eng, envs, cfg = self.E, self.engine, self.envs, self.config
-        if cfg.temperature_threshold:
-            # play_game drops to temperature 0 once len(action_history) reaches the threshold (self_play.py:163-170):
-            # a per-env, per-move switch the batch's single temperature row cannot express
-            raise NotImplementedError("play_moves does not apply config.temperature_threshold; use step()")
         if cfg.max_moves < envs.max_episode_steps:
             raise NotImplementedError("play_moves ends games where the environment does; max_moves is shorter")
-        if not getattr(envs, "constant_legal_actions", False):
-            return self._play_moves_device_inputs(n_moves, temperature, on_game, on_games)
+        # Everything but a fused search of a game with a constant legal set takes the device-input form of the batch:
+        # board games (legal sets change), residual networks (lock-step searches), and a temperature threshold
+        # (play_game drops to temperature 0 once len(action_history) reaches it, self_play.py:152-158: a per-env, per-move
+        # switch the kernels make from per-game move counters they keep on the device)
+        if temperature_threshold is None:
+            temperature_threshold = cfg.temperature_threshold
+        if not getattr(envs, "constant_legal_actions", False) or eng._fc_model is None or temperature_threshold:
+            return self._play_moves_device_inputs(n_moves, temperature, on_game, on_games, temperature_threshold)
         cur = self._cur
         params = (int(n_moves), float(temperature))
         if getattr(self, "_batch_ready", None) != params:
@@ -998,21 +1001,30 @@ class DeviceSelfPlay(ManyEnvLoop):
         self.moves_played += int(out["moves_done"].sum())
         return out["moves_done"].copy()
 
-    def _play_moves_device_inputs(self, n_moves, temperature, on_game, on_games):
-        """play_moves for games whose legal action set changes with every move (board games): the searches read the
-        legal sets and players to move from the environment kernels' device outputs and draw their exploration noise
-        on the device (engine.moves_prepare_device), so a whole batch -- games ending and restarting inside it -- is
-        queued without the host; afterwards every move is filed with the legal set it was searched with."""
+    def _play_moves_device_inputs(self, n_moves, temperature, on_game, on_games, temperature_threshold=None):
+        """play_moves with the batch's inputs on the device: the searches read the legal sets and players to move from the
+        environment kernels' device outputs and draw their exploration noise on the device (engine.moves_prepare_device),
+        so a whole batch -- games ending and restarting inside it -- is queued without the host; afterwards every move
+        is filed with the legal set it was searched with.  The search of a move is the fused whole-move kernel
+        (fully-connected networks) or the lock-step loop with this actor's network (residual networks)."""
         E, eng, envs = self.E, self.engine, self.envs
-        if eng._fc_model is None:
-            raise NotImplementedError("play_moves runs the fused whole-move search: a fully-connected network")
+        if getattr(self, "_batch_ready", None) or temperature_threshold:
+            # a batch of the pre-drawn form is waiting to be filed / the threshold rule needs the games' current lengths
+            self.flush(on_game, on_games)
         self._drop_batch()
         cur = self._cur
         eng.moves_prepare_device(n_moves, envs.legal, envs.num_legal, envs.to_play, temperature, True)
+        if temperature_threshold:
+            eng.moves_temperature_threshold(temperature_threshold, self._len)
         ring = self._move_ring(n_moves)
         obs_in = cur["obs_dev"]
         for m in range(n_moves):
-            eng.moves_enqueue(obs_in.reshape(E, -1).contiguous())
+            if temperature_threshold and m > 0:
+                eng.moves_finished(ring["done"][m - 1])      # games that ended with the move before restart their count
+            if eng._fc_model is not None:
+                eng.moves_enqueue(obs_in.reshape(E, -1).contiguous())
+            else:
+                eng.moves_enqueue_lockstep(self.model, obs_in)
             obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
                                   ring["obs_next"][m])
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
@@ -1037,14 +1049,17 @@ class DeviceSelfPlay(ManyEnvLoop):
     def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
         """ManyEnvLoop's pass: whole move batches on the device when the game, the network and the temperature allow
         it (play_moves), else one move at a time (step)."""
-        batchable = (moves_per_pass is not None and not temperature_threshold and not self.config.temperature_threshold
-                     and self.engine._fc_model is not None
-                     and self.config.max_moves >= self.envs.max_episode_steps
-                     and (temperature == 0 or _native.exact_inverse_temperature(temperature)))
+        device_inputs = (not getattr(self.envs, "constant_legal_actions", False) or self.engine._fc_model is None
+                         or bool(temperature_threshold))
+        batchable = (moves_per_pass is not None and self.config.max_moves >= self.envs.max_episode_steps
+                     and (temperature == 0 or _native.exact_inverse_temperature(temperature))
+                     # (a device-input batch draws its exploration noise on the GPU: the legacy gamma sampler for shapes <= 1)
+                     and (not device_inputs or 0.0 < float(self.config.root_dirichlet_alpha) <= 1.0))
         if not batchable:
             return ManyEnvLoop._play_pass(self, temperature, temperature_threshold, moves_per_pass)
         finished = []
-        self.play_moves(moves_per_pass, temperature, on_game=lambda e, gh: finished.append((e, gh)))
+        self.play_moves(moves_per_pass, temperature, on_game=lambda e, gh: finished.append((e, gh)),
+                        temperature_threshold=temperature_threshold or 0)
         self.flush(on_game=lambda e, gh: finished.append((e, gh)))
         return finished
 

@@ -289,3 +289,115 @@ def test_pipelined_actor_passes_with_weight_changes_equal_single_actor(dev, pkg)
         actor.close()
         out[kind] = sorted((e, tuple(gh.action_history), tuple(gh.root_values)) for e, gh in finished)
     assert len(out["single"]) > 20 and out["single"] == out["pipelined"]
+
+
+def _games_by_env(sp, actor_factory, script):
+    """Run `script(actor, on_games)` on a fresh actor; returns {env: [GameHistory, ...]} of the games it finished."""
+    done = {}
+    actor = actor_factory()
+
+    def on_games(batch):
+        for i, e in enumerate(batch.env_index):
+            done.setdefault(int(e), []).append(batch.history(i))
+    script(actor, on_games)
+    played = actor.moves_played
+    actor.close()
+    return done, played
+
+
+def _assert_same_games(a, b, E, at_least):
+    compared = 0
+    for e in range(E):
+        ga, gb = a.get(e, []), b.get(e, [])
+        assert len(ga) == len(gb), (e, len(ga), len(gb))
+        for x, y in zip(ga, gb):
+            assert x.action_history == y.action_history and x.reward_history == y.reward_history, e
+            assert x.to_play_history == y.to_play_history, e
+            assert np.array_equal(np.array(x.child_visits), np.array(y.child_visits)), e
+            assert x.root_values == y.root_values, e
+            assert all(np.array_equal(p, q) for p, q in zip(x.observation_history, y.observation_history)), e
+            compared += 1
+    assert compared >= at_least, compared
+
+
+@pytest.mark.parametrize("game,threshold", [("tictactoe", None), ("tictactoe", 4), ("connect4", None), ("connect4", 6)])
+def test_residual_network_self_play_in_lockstep_move_batches_equals_move_by_move(dev, pkg, game, threshold):
+    """A whole lock-step move on the device (reference self_play.py:129-182 for every env): root inference, legal sets
+    and players from the env kernels, device-drawn noise, the S simulations through the residual network (hipGraph
+    replays), SelfPlay.select_action on each tree's own stream -- with play_game's temperature threshold applied per env
+    and move (self_play.py:152-158) --, env step: `play_moves` queues batches of them with no host round trip, mixed
+    with step() calls, and files the same games -- actions, rewards, players, visit-count targets, root values,
+    observations, bit for bit -- as step() alone, which comes back to the host in every move."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games(game).MuZeroConfig()
+    config.temperature_threshold = threshold
+    if game == "connect4":
+        config.num_simulations = 30
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E = 48
+    total = 27 if game == "tictactoe" else 40
+
+    def factory():
+        return sp.DeviceSelfPlay({"weights": weights}, game, config, 0, E, use_graph=True)
+
+    def by_step(actor, on_games):
+        for _ in range(total):
+            actor.step(1.0, threshold, on_games=on_games)
+
+    def by_batches(actor, on_games):
+        played = np.zeros(E, np.int64)
+        sizes = (5, 7, 3) if game == "tictactoe" else (9, 11, 6)
+        for n in sizes:
+            played += actor.play_moves(n, 1.0, on_games=on_games)
+        actor.step(1.0, threshold, on_games=on_games)          # the two forms mix: same rows, same RNG streams
+        played += 1
+        played += actor.play_moves(total - 1 - sum(sizes), 1.0, on_games=on_games)
+        actor.flush(on_games=on_games)
+        assert (played == total).all()
+        assert actor.engine._graph is not None                  # the batches replayed the captured simulation loop
+
+    want, n_want = _games_by_env(sp, factory, by_step)
+    got, n_got = _games_by_env(sp, factory, by_batches)
+    assert n_want == n_got == E * total
+    _assert_same_games(want, got, E, at_least=E)
+    if threshold:
+        # the rule was really exercised: some game is longer than the threshold, and from there on every searched move
+        # took the most visited action
+        late = 0
+        for history in (g for gs in got.values() for g in gs):
+            for m, cv in enumerate(history.child_visits):
+                if m + 1 >= threshold:                          # len(action_history) before move m is m + 1
+                    late += 1
+                    assert history.action_history[m + 1] == int(np.argmax(cv)), (m, cv)
+        assert late > 0
+
+
+def test_cartpole_move_batches_apply_the_temperature_threshold(dev, pkg):
+    """play_moves with config.temperature_threshold on the fused path (fully-connected network, constant legal set): the
+    batch takes its device-input form and the kernel switches every env to temperature 0 at its own game's threshold;
+    same games as step()."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("cartpole").MuZeroConfig()
+    config.temperature_threshold = 5
+    config.num_simulations = 20
+    torch.manual_seed(0)
+    weights = models_mod.MuZeroNetwork(config).get_weights()    # (random weights: games of ~10-30 moves)
+    E, total = 64, 60
+
+    def factory():
+        return sp.DeviceSelfPlay({"weights": weights}, "cartpole", config, 0, E)
+
+    def by_step(actor, on_games):
+        for _ in range(total):
+            actor.step(1.0, config.temperature_threshold, on_games=on_games)
+
+    def by_batches(actor, on_games):
+        for n in (20, 25, 15):
+            actor.play_moves(n, 1.0, on_games=on_games)
+        actor.flush(on_games=on_games)
+
+    want, _ = _games_by_env(sp, factory, by_step)
+    got, _ = _games_by_env(sp, factory, by_batches)
+    _assert_same_games(want, got, E, at_least=E)
