@@ -1007,26 +1007,40 @@ class DeviceSelfPlay(ManyEnvLoop):
         so a whole batch -- games ending and restarting inside it -- is queued without the host; afterwards every move
         is filed with the legal set it was searched with.  The search of a move is the fused whole-move kernel
         (fully-connected networks) or the lock-step loop with this actor's network (residual networks)."""
-        E, eng, envs = self.E, self.engine, self.envs
+        self._device_batch_begin(n_moves, temperature, on_game, on_games, temperature_threshold)
+        for m in range(n_moves):
+            self._device_batch_move(m)
+        return self._device_batch_end(on_game, on_games)
+
+    # (the three phases are separate so that PipelinedDeviceSelfPlay can interleave the batches of its groups move by move)
+    def _device_batch_begin(self, n_moves, temperature, on_game, on_games, temperature_threshold):
+        eng, envs = self.engine, self.envs
         if getattr(self, "_batch_ready", None) or temperature_threshold:
             # a batch of the pre-drawn form is waiting to be filed / the threshold rule needs the games' current lengths
             self.flush(on_game, on_games)
         self._drop_batch()
-        cur = self._cur
         eng.moves_prepare_device(n_moves, envs.legal, envs.num_legal, envs.to_play, temperature, True)
         if temperature_threshold:
             eng.moves_temperature_threshold(temperature_threshold, self._len)
-        ring = self._move_ring(n_moves)
-        obs_in = cur["obs_dev"]
-        for m in range(n_moves):
-            if temperature_threshold and m > 0:
-                eng.moves_finished(ring["done"][m - 1])      # games that ended with the move before restart their count
-            if eng._fc_model is not None:
-                eng.moves_enqueue(obs_in.reshape(E, -1).contiguous())
-            else:
-                eng.moves_enqueue_lockstep(self.model, obs_in)
-            obs_in = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
-                                  ring["obs_next"][m])
+        self._dev_batch = dict(n_moves=n_moves, ring=self._move_ring(n_moves), obs_in=self._cur["obs_dev"],
+                               threshold=temperature_threshold)
+
+    def _device_batch_move(self, m):
+        b, eng, envs = self._dev_batch, self.engine, self.envs
+        ring = b["ring"]
+        if b["threshold"] and m > 0:
+            eng.moves_finished(ring["done"][m - 1])          # games that ended with the move before restart their count
+        if eng._fc_model is not None:
+            eng.moves_enqueue(b["obs_in"].reshape(self.E, -1).contiguous())
+        else:
+            eng.moves_enqueue_lockstep(self.model, b["obs_in"])
+        b["obs_in"] = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
+                                   ring["obs_next"][m])
+
+    def _device_batch_end(self, on_game, on_games):
+        b, eng, envs = self._dev_batch, self.engine, self.envs
+        n_moves, ring = b["n_moves"], b["ring"]
+        self._dev_batch = None
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         out = eng.moves_collect()
         inputs = eng.moves_inputs(n_moves)
@@ -1194,6 +1208,33 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
                 if prefetch:
                     actor.step_begin(one, many)      # the next move's search runs while the other groups are served
                     self._started[g] = True
+
+    def play_moves(self, n_moves, temperature, on_game=None, on_games=None, temperature_threshold=None):
+        """`n_moves` moves of every env of every group with no host round trip (DeviceSelfPlay.play_moves in its
+        device-input form): each group's batch is queued on the group's own stream, move by move in turn, so the
+        kernels of the groups fill each other's gaps (a tower workgroup's fill / epilogue / export phases leave the matrix
+        pipe idle) and one group's collect / filing runs under the other's kernels.  Returns moves played per env."""
+        cfg = self.config
+        if temperature_threshold is None:
+            temperature_threshold = cfg.temperature_threshold
+        for g, actor in enumerate(self.actors):
+            if self._started[g]:                             # (a search queued by step(): finish that move first)
+                raise RuntimeError("play_moves: a step() is half done; call step(..., prefetch=False) before batches")
+            if cfg.max_moves < actor.envs.max_episode_steps:
+                raise NotImplementedError("play_moves ends games where the environment does; max_moves is shorter")
+            one, many = self._callbacks(g, on_game, on_games)
+            with torch.cuda.stream(self.streams[g]):
+                actor._device_batch_begin(n_moves, temperature, one, many, temperature_threshold)
+        for m in range(n_moves):
+            for g, actor in enumerate(self.actors):
+                with torch.cuda.stream(self.streams[g]):
+                    actor._device_batch_move(m)
+        played = []
+        for g, actor in enumerate(self.actors):
+            one, many = self._callbacks(g, on_game, on_games)
+            with torch.cuda.stream(self.streams[g]):
+                played.append(actor._device_batch_end(one, many))
+        return numpy.concatenate(played)
 
     def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
         """ManyEnvLoop's pass; the last move of a pass queues nothing behind it (a weight pull follows)."""

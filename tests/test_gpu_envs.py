@@ -401,3 +401,31 @@ def test_cartpole_move_batches_apply_the_temperature_threshold(dev, pkg):
     want, _ = _games_by_env(sp, factory, by_step)
     got, _ = _games_by_env(sp, factory, by_batches)
     _assert_same_games(want, got, E, at_least=E)
+
+
+def test_pipelined_groups_play_lockstep_move_batches_like_one_actor(dev, pkg):
+    """PipelinedDeviceSelfPlay.play_moves: the move batches of two env groups queued on two streams, move by move in turn
+    (nothing waits for the host inside a batch); env e keeps seed `seed + e`, so the groups together file exactly the games
+    one DeviceSelfPlay of all envs files move by move -- TicTacToe residual network, temperature threshold on."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("tictactoe").MuZeroConfig()
+    config.temperature_threshold = 5
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E, total = 64, 24
+
+    def by_step(actor, on_games):
+        for _ in range(total):
+            actor.step(1.0, config.temperature_threshold, on_games=on_games)
+
+    def by_batches(actor, on_games):
+        played = np.zeros(E, np.int64)
+        for n in (7, 9, 8):
+            played += actor.play_moves(n, 1.0, on_games=on_games)
+        actor.flush(on_games=on_games)
+        assert (played == total).all()
+
+    want, _ = _games_by_env(sp, lambda: sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, use_graph=False), by_step)
+    got, _ = _games_by_env(sp, lambda: sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2,
+                                                                  use_graph=True), by_batches)
+    _assert_same_games(want, got, E, at_least=E)

@@ -48,11 +48,11 @@ def main():
     for kind in args.kinds.split(","):
         if kind == "host":
             actor = sp.BatchedSelfPlay({"weights": weights}, mod.Game, config, 0, args.envs)
-        elif kind == "device-pipelined":
+        elif kind in ("device-pipelined", "device-pipelined-batch"):
             actor = sp.PipelinedDeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs, groups=2)
         else:
             actor = sp.DeviceSelfPlay({"weights": weights}, args.game, config, 0, args.envs)
-            if kind == "device-batch":
+            if kind == "device-batch" and actor.engine._fc_model is not None:
                 actor.engine.set_fused_options("auto", publish_tree=False)
         done = [0]
 
@@ -63,7 +63,7 @@ def main():
             done[0] += len(batch)
 
         cb = dict(on_game=on_game) if kind in ("host", "device-lists") else dict(on_games=on_games)
-        if kind == "device-batch":
+        if kind in ("device-batch", "device-pipelined-batch"):
             # searches, env steps and resets queued back to back, `--batch` moves per host round trip
             for _ in range(3):                       # buffers, the native history filer, the pre-drawn next batch
                 actor.play_moves(args.batch, 1.0, **cb)
