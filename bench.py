@@ -54,10 +54,19 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_* / fp32 VALU peak (same guide)
 F16_MATRIX_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (same guide; the 2:1-sparsity figure is never used)
-# reference Python / oracle port, 1 thread, same inputs, measured in the build container (Xeon 2.1 GHz):
-# CartPole: C port 324e3 sims/s vs reference 1559 sims/s (tests/golden/g10_reference_speed.npz).  An extrapolation
-# to another CPU, kept only as a labelled side figure; `cpu_baseline.value` is the port itself.
-RHO_PORT_OVER_REFERENCE = {"cartpole": 208.0}
+# rho = oracle port / ACTUAL reference (imported from /root/reference), same inputs, measured in the build container with 1
+# process and with one process per core (tests/golden/time_reference.py -> tests/golden/g10_reference_speed_configs.json:
+# Xeon 2.1 GHz, 8 vCPU).  The port's measurement on the GPU box's host divided by rho is a LABELLED extrapolation of what
+# the reference's own Python would do there; `cpu_baseline.value` is the port itself.
+def _load_rho():
+    try:
+        data = json.load(open(os.path.join(ROOT, "tests", "golden", "g10_reference_speed_configs.json")))
+    except (OSError, ValueError):
+        return {}, None
+    return data.get("configs", {}), {k: data.get(k) for k in ("cpu", "cores", "procs", "seconds_per_leg")}
+
+
+REFERENCE_TIMING, REFERENCE_TIMING_HOST = _load_rho()
 
 # Envs (trees) per GPU and engines they are split into.  BASELINE.json fixes the env count for config #2 only (4096
 # CartPole envs); for the lock-step configs it is the actor's choice, and one MI355X (288 GB) is best used with many more
@@ -895,15 +904,27 @@ def cpu_baseline_leg(helper, name, config, seconds, workers=0):
            "sample": f"{one['moves']} moves x {config.num_simulations} sims ({one['seconds']:.1f} s), same weights and "
                      f"observation distribution; {kind_note}",
            "cpu": cpu_model, "host_cores_available": available_cores(), "os_cpu_count": os.cpu_count()}
-    if name in RHO_PORT_OVER_REFERENCE:
-        out["rho_port_over_reference_build_container"] = RHO_PORT_OVER_REFERENCE[name]
-        out["reference_equivalent_value_extrapolated"] = value / RHO_PORT_OVER_REFERENCE[name]
+    ref = REFERENCE_TIMING.get(name)
+    if ref:
+        procs = (REFERENCE_TIMING_HOST or {}).get("procs")
+        out["reference_in_build_container"] = {
+            "host": REFERENCE_TIMING_HOST, "reference_sims_per_s_1proc": ref["reference_sims_per_s_1proc"],
+            f"reference_sims_per_s_{procs}proc": ref.get(f"reference_sims_per_s_{procs}proc"),
+            "port_sims_per_s_1proc": ref["port_sims_per_s_1proc"], "rho_1proc": ref["rho_1proc"],
+            f"rho_{procs}proc": ref.get(f"rho_{procs}proc"),
+            "source": "tests/golden/g10_reference_speed_configs.json (tests/golden/time_reference.py runs the imported reference)"}
+        out["rho_port_over_reference_build_container"] = ref["rho_1proc"]
+        out["reference_equivalent_value_extrapolated"] = value / ref["rho_1proc"]
     if many:
         total = sum(o["sims"] / o["seconds"] for o in many)
         out["all_cores"] = {"value": total, "unit": "simulations/s", "cores": len(many), "kind": "port",
                             "sample": f"{len(many)} processes x {seconds:.0f} s, one per core, each as the 1-core leg "
                                       f"(seeds config.seed + worker index, muzero.py:175); wall {wall:.1f} s",
                             "per_core_value": total / len(many)}
+        if ref:
+            procs = (REFERENCE_TIMING_HOST or {}).get("procs")
+            rho_many = ref.get(f"rho_{procs}proc") or ref["rho_1proc"]
+            out["all_cores"]["reference_equivalent_value_extrapolated"] = total / rho_many
     return out
 
 

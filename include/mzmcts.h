@@ -434,6 +434,22 @@ typedef struct mzmcts_tower_layer {
 int64_t mzmcts_board_tower_blocks(int64_t batch, int32_t channels, int32_t height, int32_t width);
 int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
                        const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);
+/* A tower launch that also computes reward / value / policy heads (models.py:467-480, 500-522) from the activations while
+ * they are in LDS: head h reads the output of layer `layer` (before that layer's export_unit rescale) and writes dev
+ * f32[batch, head.outputs] logits -- conv_head_mfma_kernel's arithmetic, the same bits as mzmcts_conv_heads_multi on the
+ * exported tensor, without the export, the re-read and the second launch.  Exactly one of x / gather is given.  Covered:
+ * 16 channels on 3 x 3 boards (the board-column kernel), reduced <= 16, hidden <= 16, outputs <= 32, at most two heads
+ * per layer, heads on the last layer or on an export_unit layer.  MZMCTS_ERR_INVALID when the shape is not covered: the
+ * caller launches mzmcts_board_tower[_gathered] and mzmcts_conv_heads_multi instead. */
+typedef struct mzmcts_tower_head {
+    mzmcts_head_desc head;
+    float *out;
+    int32_t layer, reserved;
+} mzmcts_tower_head;
+struct mzmcts_tower_gather;
+int mzmcts_board_tower_heads(const float *x, const struct mzmcts_tower_gather *gather, int64_t batch, int32_t cin0,
+                             int32_t channels, int32_t height, int32_t width, const mzmcts_tower_layer *layers,
+                             int32_t n_layers, const mzmcts_tower_head *heads, int32_t n_heads, void *stream);
 /* The same tower (channels == 64) on the 16-bit matrix path at fp32 accuracy: every operand is carried as two fp16
  * halves (22 significant bits), a product as three fp16 MFMAs with fp32 accumulation -- representation error below an
  * fp32 fmaf chain's rounding, 5.3 x fewer matrix-pipe cycles (csrc/board_conv.hip).  Weights come from

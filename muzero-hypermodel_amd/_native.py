@@ -139,6 +139,8 @@ PROTOTYPES = {
     "mzmcts_board_conv_supported": (ctypes.c_int, [ctypes.c_int32] * 4),
     "mzmcts_board_conv3x3": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void]),
     "mzmcts_board_tower_blocks": (ctypes.c_int64, [ctypes.c_int64] + [ctypes.c_int32] * 3),
+    "mzmcts_board_tower_heads": (ctypes.c_int, [c_void, c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 +
+                                 [c_void, ctypes.c_int32, c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_tower": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 4 + [c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_conv_split_halfs": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32]),
     "mzmcts_board_conv_pack_split": (ctypes.c_int, [c_void, c_void, c_void] + [ctypes.c_int32] * 5 + [c_void]),
@@ -252,6 +254,11 @@ class MzHeadDesc(ctypes.Structure):
     _fields_ = [("conv_w", c_void), ("conv_b", c_void), ("fc1_w", c_void), ("fc1_b", c_void), ("fc2_w", c_void),
                 ("fc2_b", c_void), ("channels", ctypes.c_int32), ("plane", ctypes.c_int32), ("reduced", ctypes.c_int32),
                 ("hidden", ctypes.c_int32), ("outputs", ctypes.c_int32)]
+
+
+class MzTowerHead(ctypes.Structure):
+    """mzmcts_tower_head (include/mzmcts.h): a head computed inside a tower launch."""
+    _fields_ = [("head", MzHeadDesc), ("out", c_void), ("layer", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class MzHistMoves(ctypes.Structure):

@@ -27,6 +27,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
 
 #include "../../include/mzmcts.h"
 
@@ -289,6 +292,20 @@ struct TowerArgs {
     // not null: workgroup i runs only if gate[i] != 0 -- the re-run of the blocks of samples a split-precision launch
     // flagged as overflowed (same samples per workgroup in both kernels), queued behind it with no host in between
     const int32_t* gate;
+};
+
+// A reward / value / policy head computed inside a tower launch from the activations of `layer` while they are in LDS
+// (board_tower_cols_kernel): 1x1 convolution -> Linear + ELU -> Linear, reference models.py:467-480, 500-522.
+struct TowerHead {
+    mzmcts_head_desc d;
+    float* out;        // [batch][outputs]
+    int32_t layer;     // reads this layer's output (before an export_unit rescale replaces it)
+    int32_t pad;
+};
+struct TowerHeads {       // (fixed roles instead of an indexed array: the kernel addresses its argument segment statically)
+    TowerHead mid;        // one head on an export_unit layer (`mid.layer`): the reward head on the raw dynamics output
+    TowerHead last0, last1;   // up to two heads on the last layer: value and policy
+    int32_t has_mid, n_last;
 };
 
 // Diagnostic build only (-DMZ_TOWER_STAMPS, tools/stamp_tower.py): cycles of wave 0 of every workgroup per phase of the
@@ -573,6 +590,668 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         }
     }
     MZ_TSTAMP_FLUSH;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// 16-channel towers on SMALL boards (TicTacToe's 3 x 3), boards as the matrix tiles' COLUMNS (round 3).
+//
+// board_tower_kernel maps (sample, position) pairs to MFMA rows: its 8 wavefronts share the rows of a workgroup's boards,
+// so every layer ends in a workgroup barrier, an LDS round trip of the activations with padded planes, and a single
+// accumulator chain per wavefront; a third of its time is MFMA (profiles/r02_tower_phase_stamps.jsonl).  On a 3 x 3 board
+// all of that can go.  Here a WAVEFRONT owns 16 whole boards -- the 16 columns of every MFMA -- and an output position
+// p is a tile: D[channel][board] (16 x 16) = sum over the taps that stay inside the board of W_tap[channel][c] x
+// X[board][p + tap][c].  Consequences:
+//   * a layer's whole input for the wavefront's boards is NINE 16-byte LDS reads per lane (x[p'] = four channels of
+//     position p' of the lane's board), its weights NINE more (one 16 x 16 block per tap, shared by all tiles): every
+//     operand of the layer's 196 MFMAs (49 (position, tap) pairs inside the board x 4 channel steps) is in registers
+//     before the first one issues -- taps that fall outside the board are not multiplied by padding zeros, they are
+//     skipped (40 % of the products of the padded-plane form), and nine independent accumulator chains keep the matrix
+//     pipe full from one wavefront;
+//   * no wavefront ever needs another wavefront's activations: NO barrier between layers, the layer's output overwrites
+//     its input in LDS in place (the input is in registers), the skip connection of a residual block waits in registers;
+//   * the weights of ALL layers (9 KB each) are staged into LDS once per workgroup of 128 boards.
+// Arithmetic: per output the same k-ordered chain of fused multiply-adds as board_tower_kernel -- taps ascending, inside a
+// tap the channel steps {g, 4 + g, 8 + g, 12 + g}, g = 0..3, then the 17th input channel (the dynamics input's action
+// plane) -- minus terms that are exact zeros there (w x padding zero), and the same epilogue operations: BIT-IDENTICAL
+// outputs (tests/test_gpu_board_conv.py compares the two kernels).  Reads the weights as mzmcts_board_conv_pack lays them
+// out (its [tap][group][kk][cout][g] order is this kernel's operand order).
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kColWaves = 4;                  // wavefronts per workgroup (independent of each other): 64 boards
+constexpr int kColBoardStride = 148;          // floats between two boards' [9][16] activations (+4: bank spread of 16-byte reads)
+constexpr int kColActStride = 12;             // floats between two boards' 17th-channel values [9]
+constexpr int kColWaveFloats = 16 * (kColBoardStride + kColActStride) + 32;   // + the boards' input rows (16 pointers)
+
+// Orders this wavefront's LDS writes before its following LDS reads of other lanes' data; no other wavefront is involved.
+__device__ __forceinline__ void cols_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The three layers of a head for the wavefront's 16 boards (= the 16 samples of a tile), on the matrix cores, with the
+// arithmetic of conv_head_mfma_kernel (net_kernels.hip mfma_head_tiles) operation for operation -- the same k-ordered
+// chains (1x1 convolution: channel steps 4 ks + kk; Linear + ELU: four partial chains over the steps s = q (mod 4), added
+// in order; Linear: one chain) -- so a fused launch returns that kernel's logits bit for bit.
+//   conv_y     the 1x1 convolution of the activations in `xw` ([board][position][16 channels]): D[reduced channel][board]
+//              per position, kept in registers
+//   finish     y -> LDS as [board][r P + p] (over the activations, which the caller no longer needs), the two Linear
+//              layers, logits to global
+// a head's weights as the lane's MFMA operands, asked for from global memory (L2-resident: every wavefront reads the same
+// few KB) BEFORE the arithmetic that needs them: the round trips run under the tower's last products
+struct ColsHeadConv {
+    float conv[4];          // 1x1 convolution: W[r = lane & 15][4 ks + kk]
+    float conv_bias[4];     // bias[4 kk + r']
+};
+template <int P>
+struct ColsHeadFc {
+    const float* fc1;       // Linear 1 weights in LDS: [unit][R P + 1], staged once per workgroup (cols_stage_head)
+    float fc1_bias;
+    float fc2[2][4];        // Linear 2, column tile n, k-step ks: W2[16 n + (lane & 15)][4 ks + kk]   (hidden <= 16)
+    float fc2_bias[2];
+};
+
+__device__ __forceinline__ void cols_head_load_conv(const mzmcts_head_desc& d, int lane, ColsHeadConv& w) {
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w.conv[ks] = i < d.reduced ? d.conv_w[i * 16 + 4 * ks + kk] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) w.conv_bias[rr] = 4 * kk + rr < d.reduced ? d.conv_b[4 * kk + rr] : 0.f;
+}
+
+constexpr int kColHeadW1Floats = 16 * (16 * 9 + 1);          // LDS floats of one head's Linear-1 weights, worst case
+
+// Linear-1 weights of a head -> LDS [unit][R P + 1] by the whole workgroup (rows beyond `hidden` are never read)
+__device__ __forceinline__ void cols_stage_head(const mzmcts_head_desc& d, float* dst, int P, int tid, int nthreads) {
+    const int RP = d.reduced * P, n = d.hidden * RP;
+    for (int idx = tid; idx < n; idx += nthreads) {
+        const int u = idx / RP, k = idx - u * RP;
+        dst[u * (RP + 1) + k] = d.fc1_w[idx];
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void cols_head_load_fc(const mzmcts_head_desc& d, const float* w1_lds, int lane, ColsHeadFc<P>& w) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int Hd = d.hidden, O = d.outputs;
+    w.fc1 = w1_lds;
+    w.fc1_bias = i < Hd ? d.fc1_b[i] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + kk;
+            w.fc2[n][ks] = (k < Hd && 16 * n + i < O) ? d.fc2_w[(16 * n + i) * Hd + k] : 0.f;
+        }
+        w.fc2_bias[n] = 16 * n + i < O ? d.fc2_b[16 * n + i] : 0.f;
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void cols_head_conv(const ColsHeadConv& w, const float* xw, int lane, f32x4 (&acc)[P]) {
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int p0 = 0; p0 < P; ++p0) acc[p0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p0 = 0; p0 < P; ++p0)
+            acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.conv[ks], xw[i * kColBoardStride + p0 * 16 + 4 * ks + kk], acc[p0], 0, 0, 0);
+}
+
+template <int P>
+__device__ __forceinline__ void cols_head_finish(const TowerHead& hd, const ColsHeadConv& cw, const ColsHeadFc<P>& w,
+                                                 const f32x4 (&y)[P], float* ys, float* hs, int b0, int n_boards, int lane) {
+    const mzmcts_head_desc& d = hd.d;
+    const int i = lane & 15, kk = lane >> 4;
+    const int R = d.reduced, RP = R * P, Hd = d.hidden, O = d.outputs;
+    const int ys_stride = RP + 1, hs_stride = Hd + 1;
+    // y[board = i][r P + p] = D[r = 4 kk + r'][board] + bias[r]
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        if (4 * kk + rr < R) {
+#pragma unroll
+            for (int p0 = 0; p0 < P; ++p0) ys[i * ys_stride + (4 * kk + rr) * P + p0] = y[p0][rr] + cw.conv_bias[rr];
+        }
+    }
+    cols_wave_sync();
+    {   // Linear + ELU: h[sample][unit] = elu(sum_k y[sample][k] W1[unit][k] + b1[unit]); hidden <= 16: one column tile,
+        // four partial chains over the k-steps s = q (mod 4), added in order (mfma_head_tiles, kParts = 4)
+        f32x4 part[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int steps = (RP + 3) / 4;
+        for (int ks0 = 0; ks0 < steps; ks0 += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (ks0 + q) + kk;
+                const bool in = ks0 + q < steps && k < RP;
+                const float yv = in ? ys[i * ys_stride + k] : 0.f;
+                const float wv = (in && i < Hd) ? w.fc1[i * ys_stride + k] : 0.f;
+                part[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, wv, part[q], 0, 0, 0);
+            }
+        }
+        f32x4 acc = part[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) acc = acc + part[q];
+        if (i < Hd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[r] + w.fc1_bias;
+                hs[(4 * kk + r) * hs_stride + i] = v > 0.f ? v : expf(v) - 1.f;
+            }
+        }
+    }
+    cols_wave_sync();
+    {   // Linear: logits[sample][o], outputs <= 32: one or two column tiles
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int steps = (Hd + 3) / 4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < steps) {
+                const int k = 4 * ks + kk;
+                const float a = k < Hd ? hs[i * hs_stride + k] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if (16 * n < O) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.fc2[n][ks], acc[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int o = 16 * n + i;
+            if (o < O) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 4 * kk + r;
+                    if (q < n_boards) hd.out[static_cast<size_t>(b0 + q) * O + o] = acc[n][r] + w.fc2_bias[n];
+                }
+            }
+        }
+    }
+    cols_wave_sync();   // (the caller rewrites ys / hs)
+}
+
+// HEADS = false is the production instantiation; HEADS = true also computes heads in the launch (opt-in, MZ_TOWER_HEADS=on:
+// bit-identical logits, but measured SLOWER than tower + conv_head_mfma_kernel -- 65536 TicTacToe boards: 262 us against 130 +
+// 73 us -- because the extra live state spills registers at two wavefronts per SIMD and a head is a serial chain of three
+// small GEMMs; a separate instantiation so that the plain tower keeps its registers).
+template <int H, int W, bool HEADS>
+__global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void board_tower_cols_kernel(const float* __restrict__ x, int batch, int cin0,
+                                                                          TowerArgs args, TowerGather gather, TowerHeads heads) {
+    constexpr int P = H * W;
+    static_assert(P == 9, "written for 3 x 3 boards: 9 positions = 9 tiles, 36 accumulator registers");
+    constexpr int ROW = 16 * P;                                     // floats of a board's 16 planes (NCHW)
+    constexpr int FILL = 16 * ROW / 64;                             // = 36 values per lane: the wavefront's 16 boards
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int board = lane & 15, kk = lane >> 4;
+    const int b0 = (blockIdx.x * kColWaves + wave) * 16;          // first board of this wavefront
+    const int n_boards = min(16, batch - b0);
+    // heads inside the launch: their Linear-1 weights (the only operand too big for registers) go to LDS once per workgroup
+    float* w1_lds = lds + kColWaves * kColWaveFloats;               // [mid | last0 | last1][16][R P + 1]
+    if (HEADS && (heads.has_mid | heads.n_last)) {
+        if (heads.has_mid) cols_stage_head(heads.mid.d, w1_lds, P, tid, 64 * kColWaves);
+        if (heads.n_last > 0) cols_stage_head(heads.last0.d, w1_lds + kColHeadW1Floats, P, tid, 64 * kColWaves);
+        if (heads.n_last > 1) cols_stage_head(heads.last1.d, w1_lds + 2 * kColHeadW1Floats, P, tid, 64 * kColWaves);
+        __syncthreads();                                             // (the only barrier; every wavefront is still here)
+    }
+    if (n_boards <= 0) return;                                      // (wavefronts are independent from here on)
+    float* xw = lds + wave * kColWaveFloats;                        // [16 boards][9][16] (+ pad)
+    float* xact = xw + 16 * kColBoardStride;                        // [16 boards][9]: the 17th input channel
+    const float** in_row = reinterpret_cast<const float**>(xact + 16 * kColActStride);
+
+    // this lane's slice of a layer's weights, straight from the packed global buffer (L2 / L1 resident: every wavefront
+    // of the launch reads the same 9 KB per layer): one 16 x 4 block per tap, + the 17th channel's column
+    struct LayerWeights {
+        f32x4 w[9];
+    };
+    auto load_weights = [&](int l, LayerWeights& out) {
+        const int ng = conv_groups(args.layer[l].cin);
+        const f32x4* wq = reinterpret_cast<const f32x4*>(args.layer[l].wt);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out.w[t] = wq[((t * ng) * 4 + kk) * 16 + board];   // (lane & 15 = the output channel here)
+    };
+    LayerWeights wcur;
+
+    // ---- the tower's input: [board][position][channel] (+ the 17th channel apart); all loads issued, then stored --------
+    if (lane < 16) {
+        const long long b = b0 + lane;
+        const float* row = nullptr;
+        if (lane < n_boards)
+            row = gather.pool ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden
+                              : x + static_cast<size_t>(b) * cin0 * P;
+        in_row[lane] = row;
+    }
+    {
+        float v[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {                         // idx = (board q, channel c, position p), NCHW order
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const float* row = in_row[q];
+            v[it] = row ? row[cp] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const int c = cp / P, p0 = cp - c * P;
+            xw[q * kColBoardStride + p0 * 16 + c] = v[it];
+        }
+#pragma unroll
+        for (int it = 0; it < (16 * P + 63) / 64; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < 16 * P) {
+                const int q = idx / P, p0 = idx - q * P;
+                const float* row = in_row[q];
+                float a = 0.f;
+                if (row && cin0 == 17)
+                    a = gather.pool ? static_cast<float>(gather.action[b0 + q]) / gather.action_space : row[16 * P + p0];
+                xact[q * kColActStride + p0] = a;
+            }
+        }
+    }
+
+    load_weights(0, wcur);
+    float wact[9];                                                  // layer 0 only (tower_cols_applies: later layers read 16 channels)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        wact[t] = cin0 == 17 ? reinterpret_cast<const f32x4*>(args.layer[0].wt)[((t * 2 + 1) * 4 + kk) * 16 + board][0] : 0.f;
+
+    auto export_planes = [&](float* out) {                          // NCHW [batch][16][P]: consecutive lanes, consecutive addresses
+        float v[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const int c = cp / P, p0 = cp - c * P;
+            v[it] = xw[q * kColBoardStride + p0 * 16 + c];
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < n_boards * ROW) out[static_cast<size_t>(b0) * ROW + idx] = v[it];
+        }
+    };
+
+    f32x4 xr[P], prev[P];
+#pragma unroll
+    for (int p0 = 0; p0 < P; ++p0) prev[p0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < args.n_layers; ++l) {
+        const TowerLayer& L = args.layer[l];
+        const bool has_act = l == 0 && cin0 == 17;                  // 17 input channels: the dynamics input's action plane
+        // operands: this lane's four channels of every position of its board (the weights were asked for a layer ago)
+#pragma unroll
+        for (int p0 = 0; p0 < P; ++p0) xr[p0] = *reinterpret_cast<const f32x4*>(xw + board * kColBoardStride + p0 * 16 + 4 * kk);
+        float xav[P];
+#pragma unroll
+        for (int p0 = 0; p0 < P; ++p0) xav[p0] = 0.f;
+        if (has_act) {      // channel 16 = step g = 0 of the second channel group; lanes kk > 0 carry that group's zero padding
+#pragma unroll
+            for (int p0 = 0; p0 < P; ++p0) xav[p0] = kk == 0 ? xact[board * kColActStride + p0] : 0.f;
+        }
+        const float4 s4 = *reinterpret_cast<const float4*>(L.scale + 4 * kk);
+        const float4 h4v = *reinterpret_cast<const float4*>(L.shift + 4 * kk);
+        const f32x4 sc = {s4.x, s4.y, s4.z, s4.w}, sh = {h4v.x, h4v.y, h4v.z, h4v.w};
+        const int skip = L.skip, relu = L.relu;
+
+        f32x4 acc[P];
+#pragma unroll
+        for (int p0 = 0; p0 < P; ++p0) acc[p0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // taps outermost: consecutive MFMAs belong to different tiles (independent chains); per tile the order is taps
+        // ascending, channel steps ascending, then the 17th channel -- board_tower_kernel's chain without its zero terms
+        auto products = [&](auto with_act) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int p0 = 0; p0 < P; ++p0) {
+                        const int y = p0 / W + dy, xx = p0 % W + dx;
+                        if (y < 0 || y >= H || xx < 0 || xx >= W) continue;      // (compile-time: the loops are unrolled)
+                        acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur.w[t][g], xr[y * W + xx][g], acc[p0], 0, 0, 0);
+                    }
+                }
+                if constexpr (decltype(with_act)::value) {
+#pragma unroll
+                    for (int p0 = 0; p0 < P; ++p0) {
+                        const int y = p0 / W + dy, xx = p0 % W + dx;
+                        if (y < 0 || y >= H || xx < 0 || xx >= W) continue;
+                        acc[p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wact[t], xav[y * W + xx], acc[p0], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if (has_act) products(std::true_type{}); else products(std::false_type{});
+        // ---- epilogue, in place: D[channel = 4 kk + r][board] of tile p -> [board][p][4 kk .. 4 kk + 3] ----------------
+        f32x4 v[P];
+#pragma unroll
+        for (int p0 = 0; p0 < P; ++p0) {
+            v[p0] = acc[p0] * sc + sh;
+            if (skip) v[p0] = v[p0] + prev[p0];                      // the residual block's input: last layer's operand
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[p0][r] = v[p0][r] < 0.f ? 0.f : v[p0][r];
+            }
+            prev[p0] = xr[p0];
+        }
+        auto store_planes = [&]() {
+            if (board < n_boards) {
+#pragma unroll
+                for (int p0 = 0; p0 < P; ++p0) *reinterpret_cast<f32x4*>(xw + board * kColBoardStride + p0 * 16 + 4 * kk) = v[p0];
+            }
+        };
+        store_planes();
+        if (L.export_raw) export_planes(L.export_raw);
+        // heads reading this layer's output (host-checked: only where the activations are rewritten afterwards -- an
+        // export_unit layer -- or no longer needed -- the last layer --, because y and h take their place in LDS)
+        if constexpr (HEADS) {
+            float* ys = xw;                                          // [16][R P + 1] <= 16 x 145 floats
+            float* hs = xw + 16 * (16 * P + 1);                      // [16][hidden + 1] <= 272 floats: the rest of the region
+            if (heads.has_mid && heads.mid.layer == l) {
+                ColsHeadConv c0;
+                ColsHeadFc<P> f0;
+                cols_head_load_conv(heads.mid.d, lane, c0);
+                cols_head_load_fc<P>(heads.mid.d, w1_lds, lane, f0);         // (asked for before the arithmetic that needs them)
+                cols_wave_sync();                                    // (the planes just stored, read across lanes)
+                f32x4 y0[P];
+                cols_head_conv<P>(c0, xw, lane, y0);
+                cols_wave_sync();                                    // (every lane has read the planes: y may overwrite them)
+                cols_head_finish<P>(heads.mid, c0, f0, y0, ys, hs, b0, n_boards, lane);
+            }
+            if (heads.n_last > 0 && l == args.n_layers - 1) {
+                ColsHeadConv c0, c1;
+                ColsHeadFc<P> f0, f1;
+                cols_head_load_conv(heads.last0.d, lane, c0);
+                if (heads.n_last > 1) cols_head_load_conv(heads.last1.d, lane, c1);
+                cols_head_load_fc<P>(heads.last0.d, w1_lds + kColHeadW1Floats, lane, f0);
+                cols_wave_sync();
+                f32x4 y0[P], y1[P];
+                cols_head_conv<P>(c0, xw, lane, y0);
+                if (heads.n_last > 1) cols_head_conv<P>(c1, xw, lane, y1);
+                cols_wave_sync();
+                if (heads.n_last > 1) cols_head_load_fc<P>(heads.last1.d, w1_lds + 2 * kColHeadW1Floats, lane, f1);   // in flight under the first head's layers
+                cols_head_finish<P>(heads.last0, c0, f0, y0, ys, hs, b0, n_boards, lane);
+                if (heads.n_last > 1) cols_head_finish<P>(heads.last1, c1, f1, y1, ys, hs, b0, n_boards, lane);
+            }
+        }
+        if (L.export_unit) {
+            // per (board, channel) plane: (x - min) / span -- models.py:525-549, the operations of unit_rescale_kernel in
+            // the same order; a plane's nine values are element r of this lane's nine registers
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float lo = v[0][r], hi = lo;
+#pragma unroll
+                for (int p0 = 1; p0 < P; ++p0) {
+                    const float u = v[p0][r];
+                    lo = (u < lo || u != u) ? u : lo;
+                    hi = (u > hi || u != u) ? u : hi;
+                }
+                float span = hi - lo;
+                if (span < 1e-5f) span = span + 1e-5f;
+#pragma unroll
+                for (int p0 = 0; p0 < P; ++p0) v[p0][r] = (v[p0][r] - lo) / span;
+            }
+            store_planes();
+            export_planes(L.export_unit);
+        }
+        if (l + 1 < args.n_layers) load_weights(l + 1, wcur);        // in flight under the next layer's operand reads
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// The same idea for boards made of several 3 x 3 PATCHES (6 x 6: the 84 x 84 configuration's hidden state): an MFMA
+// column is a (board, patch) pair -- 16 columns = 4 boards x 4 patches per wavefront --, a tile one of the patch's nine
+// positions, and a lane's operands are the 5 x 5 halo around its patch (cells outside the board are zeros, cells of the
+// neighbouring patches come from the same wavefront's LDS: all of a board's patches live in one wavefront, so there is
+// still no barrier and the layer still overwrites its input in place once every lane has read its halo).  No product is
+// skipped here (which halo cells are outside depends on the lane's patch), so the arithmetic is board_tower_kernel's chain
+// term for term: bit-identical outputs.  The residual block's input waits in a second LDS buffer (the registers are taken
+// by the 25 halo operands).
+// -------------------------------------------------------------------------------------------------------------------
+template <int H, int W>
+struct PatchGeometry {
+    static constexpr int P = H * W;
+    static constexpr int NPX = W / 3, NPY = H / 3, NP = NPX * NPY;    // patches per board
+    static constexpr int BPW = 16 / NP;                                // boards per wavefront
+    static constexpr int BS = P * 16 + 4;                              // floats between two boards' [P][16] activations
+    static constexpr int WAVE_FLOATS = 2 * BPW * BS + BPW * P + 32;    // activations | skip | 17th channel | input rows
+    static_assert(H % 3 == 0 && W % 3 == 0 && 16 % NP == 0 && NP > 1, "boards of 2, 4, 8 or 16 patches of 3 x 3");
+    static_assert((BPW * 16 * P) % 64 == 0, "the fill walks whole wavefronts");
+};
+
+template <int H, int W>
+__global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void board_tower_patch_kernel(
+    const float* __restrict__ x, int batch, int cin0, TowerArgs args, TowerGather gather) {
+    using G = PatchGeometry<H, W>;
+    constexpr int P = G::P, NP = G::NP, NPX = G::NPX, BPW = G::BPW, BS = G::BS;
+    constexpr int ROW = 16 * P;
+    constexpr int FILL = BPW * ROW / 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int bl = col / NP, patch = col % NP;                       // this lane's board (in the wavefront) and patch
+    const int py = (patch / NPX) * 3, px = (patch % NPX) * 3;
+    const int b0 = (blockIdx.x * kColWaves + wave) * BPW;
+    const int n_boards = min(BPW, batch - b0);
+    if (n_boards <= 0) return;                                      // (no barrier anywhere: wavefronts are independent)
+    float* xw = lds + wave * G::WAVE_FLOATS;                         // [BPW][P][16]
+    float* xskip = xw + BPW * BS;                                    // the residual block's input, same layout
+    float* xact = xskip + BPW * BS;                                  // [BPW][P]: the 17th input channel
+    const float** in_row = reinterpret_cast<const float**>(xact + BPW * P);
+
+    if (lane < BPW) {
+        const long long b = b0 + lane;
+        const float* row = nullptr;
+        if (lane < n_boards)
+            row = gather.pool ? gather.pool + (static_cast<size_t>(gather.parent[b]) * gather.envs + b) * gather.hidden
+                              : x + static_cast<size_t>(b) * cin0 * P;
+        in_row[lane] = row;
+    }
+    {
+        float v[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {                         // idx = (board q, channel c, position p), NCHW order
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const float* row = in_row[q];
+            v[it] = row ? row[cp] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const int c = cp / P, p0 = cp - c * P;
+            xw[q * BS + p0 * 16 + c] = v[it];
+        }
+        for (int idx = lane; idx < BPW * P; idx += 64) {
+            const int q = idx / P, p0 = idx - q * P;
+            const float* row = in_row[q];
+            float a = 0.f;
+            if (row && cin0 == 17)
+                a = gather.pool ? static_cast<float>(gather.action[b0 + q]) / gather.action_space : row[16 * P + p0];
+            xact[idx] = a;
+        }
+    }
+    f32x4 wcur[9];
+    auto load_weights = [&](int l) {
+        const int ng = conv_groups(args.layer[l].cin);
+        const f32x4* wq = reinterpret_cast<const f32x4*>(args.layer[l].wt);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wcur[t] = wq[((t * ng) * 4 + kk) * 16 + col];      // (lane & 15 = the output channel here)
+    };
+    load_weights(0);
+    float wact[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        wact[t] = cin0 == 17 ? reinterpret_cast<const f32x4*>(args.layer[0].wt)[((t * 2 + 1) * 4 + kk) * 16 + col][0] : 0.f;
+
+    auto export_planes = [&](float* out) {
+        float v[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const int c = cp / P, p0 = cp - c * P;
+            v[it] = xw[q * BS + p0 * 16 + c];
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < n_boards * ROW) out[static_cast<size_t>(b0) * ROW + idx] = v[it];
+        }
+    };
+    // halo cell (hy, hx) in 0..4 of this lane's patch: board position, or outside the board
+    auto cell = [&](int hy, int hx, bool& inside) {
+        const int y = py + hy - 1, xx = px + hx - 1;
+        inside = y >= 0 && y < H && xx >= 0 && xx < W;
+        return inside ? y * W + xx : 0;
+    };
+
+    for (int l = 0; l < args.n_layers; ++l) {
+        const TowerLayer& L = args.layer[l];
+        const bool has_act = l == 0 && cin0 == 17;
+        const bool next_skips = l + 1 < args.n_layers && args.layer[l + 1].skip;
+        f32x4 xr[25];
+#pragma unroll
+        for (int h = 0; h < 25; ++h) {
+            bool inside;
+            const int pos = cell(h / 5, h % 5, inside);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xw + bl * BS + pos * 16 + 4 * kk);
+            xr[h] = inside ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (next_skips) {                                            // this layer's input is the next layer's skip connection
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pos = (py + t / 3) * W + px + t % 3;
+                *reinterpret_cast<f32x4*>(xskip + bl * BS + pos * 16 + 4 * kk) = xr[(t / 3 + 1) * 5 + t % 3 + 1];
+            }
+        }
+        const float4 s4 = *reinterpret_cast<const float4*>(L.scale + 4 * kk);
+        const float4 h4v = *reinterpret_cast<const float4*>(L.shift + 4 * kk);
+        const f32x4 sc = {s4.x, s4.y, s4.z, s4.w}, sh = {h4v.x, h4v.y, h4v.z, h4v.w};
+        const int skip = L.skip, relu = L.relu;
+
+        f32x4 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto products = [&](auto with_act) {
+            float xav[25];
+            if constexpr (decltype(with_act)::value) {
+#pragma unroll
+                for (int h = 0; h < 25; ++h) {
+                    bool inside;
+                    const int pos = cell(h / 5, h % 5, inside);
+                    const float a = xact[bl * P + pos];
+                    xav[h] = (inside && kk == 0) ? a : 0.f;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[tap][g], xr[(t / 3 + tap / 3) * 5 + t % 3 + tap % 3][g], acc[t], 0, 0, 0);
+                if constexpr (decltype(with_act)::value) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wact[tap], xav[(t / 3 + tap / 3) * 5 + t % 3 + tap % 3], acc[t], 0, 0, 0);
+                }
+            }
+        };
+        if (has_act) products(std::true_type{}); else products(std::false_type{});
+
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pos = (py + t / 3) * W + px + t % 3;
+            f32x4 v = acc[t] * sc + sh;
+            if (skip) v = v + *reinterpret_cast<const f32x4*>(xskip + bl * BS + pos * 16 + 4 * kk);
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? 0.f : v[r];
+            }
+            if (bl < n_boards) *reinterpret_cast<f32x4*>(xw + bl * BS + pos * 16 + 4 * kk) = v;
+        }
+        if (l + 1 < args.n_layers) load_weights(l + 1);
+        if (L.export_raw || L.export_unit) {
+            cols_wave_sync();                                        // (planes written by other lanes of the wavefront)
+            if (L.export_raw) export_planes(L.export_raw);
+            if (L.export_unit) {
+                // per (board, channel) plane, sequentially over its positions: models.py:525-549, unit_rescale_kernel's operations
+                for (int q = lane; q < n_boards * 16; q += 64) {
+                    float* plane = xw + (q >> 4) * BS + (q & 15);
+                    float lo = plane[0], hi = lo;
+                    for (int p0 = 1; p0 < P; ++p0) {
+                        const float u = plane[p0 * 16];
+                        lo = (u < lo || u != u) ? u : lo;
+                        hi = (u > hi || u != u) ? u : hi;
+                    }
+                    float span = hi - lo;
+                    if (span < 1e-5f) span = span + 1e-5f;
+                    for (int p0 = 0; p0 < P; ++p0) plane[p0 * 16] = (plane[p0 * 16] - lo) / span;
+                }
+                cols_wave_sync();
+                export_planes(L.export_unit);
+            }
+        }
+        cols_wave_sync();                                            // (the next layer's halo reads cross lanes)
+    }
+}
+
+static int launch_board_tower_patch66(const float* x, int batch, int cin0, const TowerArgs& args, hipStream_t stream,
+                                      const TowerGather& gather) {
+    using G = PatchGeometry<6, 6>;
+    for (int l = 0; l < args.n_layers; ++l)
+        if (reinterpret_cast<uintptr_t>(args.layer[l].wt) & 15u) return MZMCTS_ERR_INVALID;   // (read as float4)
+    const size_t lds = sizeof(float) * static_cast<size_t>(kColWaves) * G::WAVE_FLOATS;
+    auto kernel = board_tower_patch_kernel<6, 6>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds)) != hipSuccess)
+        return MZMCTS_ERR_HIP;
+    const int per_group = G::BPW * kColWaves;
+    kernel<<<dim3(static_cast<unsigned>((batch + per_group - 1) / per_group)), dim3(64 * kColWaves), lds, stream>>>(x, batch, cin0,
+                                                                                                                  args, gather);
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
+static bool tower_cols_applies(int channels, int height, int width, int cin0, const TowerArgs& args) {
+    const char* env = std::getenv("MZ_TOWER_COLS");              // "off": the row-tile kernel (A/B runs, the equality test)
+    const bool off = env && std::string(env) == "off";
+    const bool board = (height == 3 && width == 3) || (height == 6 && width == 6);
+    if (off || channels != 16 || !board || (cin0 != 16 && cin0 != 17)) return false;
+    for (int l = 1; l < args.n_layers; ++l)
+        if (args.layer[l].cin != 16) return false;
+    return true;
+}
+
+static int launch_board_tower_cols(const float* x, int batch, int cin0, const TowerArgs& args, hipStream_t stream,
+                                   const TowerGather& gather, const TowerHeads& heads = TowerHeads{}) {
+    static_assert(16 * (16 * 9 + 1) + 16 * 17 <= kColWaveFloats, "a head's y and h take the place of the activations");
+    auto head_ok = [&](const TowerHead& hd) {
+        const mzmcts_head_desc& d = hd.d;
+        return hd.out && d.conv_w && d.conv_b && d.fc1_w && d.fc1_b && d.fc2_w && d.fc2_b && d.channels == 16 && d.plane == 9 &&
+               d.reduced >= 1 && d.reduced <= 16 && d.hidden >= 1 && d.hidden <= 16 && d.outputs >= 1 && d.outputs <= 32;
+    };
+    if (heads.has_mid && !(head_ok(heads.mid) && heads.mid.layer >= 0 && heads.mid.layer < args.n_layers - 1 &&
+                           args.layer[heads.mid.layer].export_unit))
+        return MZMCTS_ERR_INVALID;
+    if (heads.n_last < 0 || heads.n_last > 2 || (heads.n_last > 0 && !head_ok(heads.last0)) || (heads.n_last > 1 && !head_ok(heads.last1)))
+        return MZMCTS_ERR_INVALID;
+    const bool with_heads = heads.has_mid || heads.n_last > 0;
+    const size_t lds = sizeof(float) * (static_cast<size_t>(kColWaves) * kColWaveFloats + (with_heads ? 3 * kColHeadW1Floats : 0));
+    const int per_group = 16 * kColWaves;
+    const dim3 grid(static_cast<unsigned>((batch + per_group - 1) / per_group)), block(64 * kColWaves);
+    if (with_heads) {
+        auto kernel = board_tower_cols_kernel<3, 3, true>;
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   static_cast<int>(lds)) != hipSuccess)
+            return MZMCTS_ERR_HIP;
+        kernel<<<grid, block, lds, stream>>>(x, batch, cin0, args, gather, heads);
+    } else {
+        board_tower_cols_kernel<3, 3, false><<<grid, block, lds, stream>>>(x, batch, cin0, args, gather, heads);
+    }
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
 template <int NT, int H, int W, int SB>
@@ -1116,10 +1795,24 @@ extern "C" int mzmcts_board_conv3x3(const float* x, const float* packed, const f
 }
 
 static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64_t batch, int32_t cin0, int32_t channels,
-                            int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_) {
+                            int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_,
+                            const mzmcts_tower_head* heads = nullptr, int32_t n_heads = 0) {
     if ((!x && !gather.pool) || !layers || batch < 0 || batch > 0x3fffffff || n_layers < 1 || n_layers > mz::kMaxTowerLayers ||
-        !mzmcts_board_conv_supported(cin0, channels, height, width))
+        !mzmcts_board_conv_supported(cin0, channels, height, width) || n_heads < 0 || n_heads > 3 || (n_heads > 0 && !heads))
         return MZMCTS_ERR_INVALID;
+    mz::TowerHeads th{};
+    for (int q = 0; q < n_heads; ++q) {
+        const mz::TowerHead hd{heads[q].head, heads[q].out, heads[q].layer, 0};
+        if (hd.layer == n_layers - 1) {
+            if (th.n_last >= 2) return MZMCTS_ERR_INVALID;
+            (th.n_last == 0 ? th.last0 : th.last1) = hd;
+            ++th.n_last;
+        } else {
+            if (th.has_mid) return MZMCTS_ERR_INVALID;
+            th.mid = hd;
+            th.has_mid = 1;
+        }
+    }
     mz::TowerArgs args{};
     args.n_layers = n_layers;
     for (int l = 0; l < n_layers; ++l) {
@@ -1131,6 +1824,9 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     }
     args.gate = layers[0].gate;
     if (args.gate && channels != 64) return MZMCTS_ERR_INVALID;   // (the hand-over exists between the two 64-channel forms)
+    // heads inside the launch: the 3 x 3 board-column kernel only -- decided before anything is launched
+    if (n_heads > 0 && !(height == 3 && width == 3 && mz::tower_cols_applies(channels, height, width, cin0, args)))
+        return MZMCTS_ERR_INVALID;
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
@@ -1150,10 +1846,19 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     }
     if (height == 6 && width == 6) {
         if (channels == 64) return mz::launch_board_tower<4, 6, 6, 4>(x, b, cin0, args, stream, gather);
+        if (mz::tower_cols_applies(channels, height, width, cin0, args)) {
+            const int rc = mz::launch_board_tower_patch66(x, b, cin0, args, stream, gather);
+            if (rc != MZMCTS_ERR_INVALID) return rc;
+        }
         if (many) return mz::launch_board_tower<1, 6, 6, 3>(x, b, cin0, args, stream, gather);
         return mz::launch_board_tower<1, 6, 6, 4>(x, b, cin0, args, stream, gather);
     }
     if (channels == 64) return mz::launch_board_tower<4, 3, 3, 16>(x, b, cin0, args, stream, gather);
+    if (mz::tower_cols_applies(channels, height, width, cin0, args)) {
+        const int rc = mz::launch_board_tower_cols(x, b, cin0, args, stream, gather, th);
+        if (rc != MZMCTS_ERR_INVALID || n_heads > 0) return rc;
+    }
+    if (n_heads > 0) return MZMCTS_ERR_INVALID;                      // (heads inside the launch: the board-column kernel only)
     if (many) return mz::launch_board_tower<1, 3, 3, 14>(x, b, cin0, args, stream, gather);
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream, gather);
 }
@@ -1176,6 +1881,20 @@ extern "C" int mzmcts_board_tower(const float* x, int64_t batch, int32_t cin0, i
                                   const mzmcts_tower_layer* layers, int32_t n_layers, void* stream) {
     if (!x) return MZMCTS_ERR_INVALID;
     return board_tower_impl(x, mz::TowerGather{}, batch, cin0, channels, height, width, layers, n_layers, stream);
+}
+
+extern "C" int mzmcts_board_tower_heads(const float* x, const mzmcts_tower_gather* g, int64_t batch, int32_t cin0,
+                                        int32_t channels, int32_t height, int32_t width, const mzmcts_tower_layer* layers,
+                                        int32_t n_layers, const mzmcts_tower_head* heads, int32_t n_heads, void* stream) {
+    if ((!x) == (!g) || n_heads < 1) return MZMCTS_ERR_INVALID;     // exactly one input form
+    mz::TowerGather gather{};
+    if (g) {
+        if (!g->pool || !g->parent || !g->action || g->envs < batch || !(g->action_space > 0.f) ||
+            g->hidden_floats != channels * height * width || cin0 != channels + 1)
+            return MZMCTS_ERR_INVALID;
+        gather = mz::TowerGather{g->pool, g->parent, g->action, static_cast<long long>(g->envs), g->hidden_floats, g->action_space};
+    }
+    return board_tower_impl(x, gather, batch, cin0, channels, height, width, layers, n_layers, stream, heads, n_heads);
 }
 
 extern "C" int64_t mzmcts_board_conv_split_halfs(int32_t cin_conv, int32_t cout) {

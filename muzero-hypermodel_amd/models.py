@@ -731,7 +731,7 @@ class MuZeroResidualNetwork(AbstractNetwork):
             layers.append((block.conv2, block.bn2, 1, 1))
         return layers
 
-    def _tower(self, x, layers, exports, const_plane=False, gather=None, shape=None, device=None):
+    def _tower(self, x, layers, exports, const_plane=False, gather=None, shape=None, device=None, heads=None):
         """Run `layers` = [(conv, bn, relu, skip)] on x in ONE launch; exports = {layer index: (raw, unit)} tensors (or
         None) that receive that layer's output / its min-max-rescaled form.  With `gather` (a _native.MzTowerGather,
         x = None, shape = (b, cin0, h, w)) the input comes straight from the search's hidden-state pool.  Returns False
@@ -758,6 +758,8 @@ class MuZeroResidualNetwork(AbstractNetwork):
         # 64-channel towers run on the 16-bit matrix path with every operand split into two fp16 halves (fp32-level
         # accuracy, csrc/board_conv.hip); MZ_BOARD_CONV_PRECISION=fp32 keeps the exact-fp32 MFMA form
         split = channels == 64 and os.environ.get("MZ_BOARD_CONV_PRECISION", "split") != "fp32"
+        if heads and split:
+            return False                                 # (heads inside the launch: the 16-channel board-column kernel)
         # The split tower's range is |activation| < 8188; it flags the blocks of samples that left it and the exact-fp32
         # tower, queued right behind it on the same stream, re-runs exactly those (include/mzmcts.h mzmcts_tower_layer.gate):
         # no NaN reaches the search, no host round trip, and the pair is captured into a hipGraph like any other launch.
@@ -784,6 +786,18 @@ class MuZeroResidualNetwork(AbstractNetwork):
             return descs, keep
 
         def launch(as_split, descs):
+            if heads:
+                # heads = [(layer index, (conv1x1, fc, flat size), out tensor)]: computed inside the launch
+                hdescs = (_native.MzTowerHead * len(heads))(*[
+                    _native.MzTowerHead(_native.MzHeadDesc(
+                        conv.weight.data_ptr(), conv.bias.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
+                        fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), channels, h * w, conv.out_channels,
+                        fc[0].out_features, fc[2].out_features), out.data_ptr(), layer, 0)
+                    for layer, (conv, fc, _), out in heads])
+                return lib.mzmcts_board_tower_heads(None if gather is not None else x.data_ptr(),
+                                                    ctypes.byref(gather) if gather is not None else None, b, cin0, channels,
+                                                    h, w, ctypes.addressof(descs), len(layers), ctypes.addressof(hdescs),
+                                                    len(heads), stream)
             if gather is not None:
                 return lib.mzmcts_board_tower_gathered(ctypes.byref(gather), b, cin0, 1 if as_split else 0, channels, h, w,
                                                        ctypes.addressof(descs), len(layers), stream)
@@ -848,6 +862,42 @@ class MuZeroResidualNetwork(AbstractNetwork):
             return None                                                  # (the last input plane is action / A)
         return raw, state, features if features is not None else state
 
+    def _recurrent_fused(self, planes, out_state, gather=None, shape=None, device=None):
+        """dynamics + rescale + prediction towers AND the three heads of recurrent_inference in ONE launch (include/mzmcts.h
+        mzmcts_board_tower_heads: the reward head reads the raw dynamics output, value and policy the prediction features,
+        all while the activations are in LDS); returns (value, reward, policy logits, next state) or None when the launch
+        does not cover this network (the caller takes the tower launch + the heads launch)."""
+        # opt-in: measured slower than the tower launch + the heads launch (65536 TicTacToe boards: 262 us against 130 + 73 us;
+        # csrc/board_conv.hip board_tower_cols_kernel<.., HEADS = true>), kept for its bit-identical results
+        if os.environ.get("MZ_TOWER_HEADS", "off") != "on":
+            return None
+        dyn, pred = self.dynamics_network.module, self.prediction_network.module
+        trios = [(dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward),
+                 (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value),
+                 (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy)]
+        for conv, fc, _ in trios:
+            if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is not None and len(fc) == 4
+                    and isinstance(fc[0], torch.nn.Linear) and isinstance(fc[1], torch.nn.ELU) and fc[1].alpha == 1.0
+                    and isinstance(fc[2], torch.nn.Linear) and isinstance(fc[3], torch.nn.Identity)):
+                return None
+        layers = [(dyn.conv, dyn.bn, 1, 0)] + self._block_layers(dyn.resblocks)
+        last_dyn = len(layers) - 1
+        layers += self._block_layers(pred.resblocks)
+        if len(layers) - 1 == last_dyn:
+            return None                                  # (no prediction blocks: all three heads would share a layer)
+        b, _, h, w = shape if gather is not None else planes.shape
+        device = device if gather is not None else planes.device
+        c = dyn.conv.out_channels
+        state = out_state if out_state is not None else torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+        if not (state.is_contiguous() and state.dtype == torch.float32 and tuple(state.shape) == (b, c, h, w)):
+            return None
+        outs = [torch.empty((b, fc[2].out_features), dtype=torch.float32, device=device) for _, fc, _ in trios]
+        heads = [(last_dyn, trios[0], outs[0]), (len(layers) - 1, trios[1], outs[1]), (len(layers) - 1, trios[2], outs[2])]
+        if not self._tower(planes, layers, {last_dyn: (None, state)}, const_plane=True, gather=gather, shape=shape,
+                           device=device, heads=heads):
+            return None
+        return outs[1], outs[0], outs[2], state
+
     def pool_towers_supported(self, batch, device, state_shape):
         """Can recurrent_inference_from_pool serve hidden states of shape `state_shape` = (channels, h, w) (inference
         mode, tower shapes the HIP library covers)?  The engine asks once per model."""
@@ -874,6 +924,9 @@ class MuZeroResidualNetwork(AbstractNetwork):
         (include/mzmcts.h mzmcts_board_tower_gathered; `gather` = engine.tower_gather() after a select())."""
         c = self.dynamics_network.module.conv.out_channels
         h, w = out_state.shape[-2], out_state.shape[-1]
+        whole = self._recurrent_fused(None, out_state, gather=gather, shape=(batch, c + 1, h, w), device=out_state.device)
+        if whole is not None:
+            return whole
         fused = self._recurrent_tower(None, out_state, gather=gather, shape=(batch, c + 1, h, w), device=out_state.device)
         if fused is None:
             raise RuntimeError("recurrent_inference_from_pool: the tower launch does not cover this network "
@@ -914,6 +967,9 @@ class MuZeroResidualNetwork(AbstractNetwork):
     def recurrent_inference_from_planes(self, planes, out_state=None):
         """recurrent_inference for a caller that already holds the dynamics input (the engine's gather writes it:
         include/mzmcts.h mzmcts_select_planes)."""
+        whole = self._recurrent_fused(planes, out_state) if planes.is_cuda and not self.training and not torch.is_grad_enabled() else None
+        if whole is not None:
+            return whole
         fused = self._recurrent_tower(planes, out_state)
         if fused is not None:
             raw, next_state, features = fused

@@ -531,8 +531,11 @@ class ManyEnvLoop:
         st = self._loop_state()
         if self._distributed() and moves_per_pass is None:
             raise ValueError("several ranks: give moves_per_pass so that every rank makes the same collective calls")
-        if test_mode and len(cfg.players) > 1 and cfg.opponent != "self":
-            raise NotImplementedError("many-env test mode plays \"self\"; use SelfPlay for expert / random opponents")
+        # test mode against an opponent (self_play.py:65-90: play_game(0, threshold, False, config.opponent,
+        # config.muzero_player) for games with several players): the actors whose step() takes an opponent play it
+        self._opponent = ("self", 0)
+        if test_mode and len(cfg.players) > 1:
+            self._opponent = (cfg.opponent, cfg.muzero_player)
         talker = not self._distributed() or torch.distributed.get_rank() == 0
         while True:
             step, stop = self._loop_control(shared_storage, cfg.training_steps)
@@ -624,15 +627,24 @@ class BatchedSelfPlay(ManyEnvLoop):
     def set_weights(self, weights):
         self.model.set_weights(weights)
 
-    def step(self, temperature, temperature_threshold=None, on_game=None):
-        """One move in every env (the body of play_game's loop, self_play.py:129-182)."""
+    def step(self, temperature, temperature_threshold=None, on_game=None, opponent=None, muzero_player=None):
+        """One move in every env (the body of play_game's loop, self_play.py:129-182).  `opponent` / `muzero_player`
+        (default: what continuous_self_play's test mode set, else "self"): in an env where it is not MuZero's turn the
+        move comes from select_opponent_action (self_play.py:189-221) -- the plugin's expert_agent(), or
+        numpy.random.choice over the legal actions drawn on THAT env's stream -- and no search statistics are stored
+        for it (root None: store_search_statistics appends only a None root value, self_play.py:497-512)."""
         cfg = self.config
+        if opponent is None:
+            opponent, muzero_player = getattr(self, "_opponent", ("self", 0))
+        if opponent not in ("self", "expert", "random"):
+            raise NotImplementedError('many-env actors play opponent "self", "expert" or "random" ("human": use SelfPlay)')
+        searching = [opponent == "self" or muzero_player == self.games[e].to_play() for e in range(self.E)]
         stacked = numpy.stack([
             self.histories[e].get_stacked_observations(-1, cfg.stacked_observations)
             for e in range(self.E)]).astype(numpy.float32)
-        legal = [self.games[e].legal_actions() for e in range(self.E)]
+        legal = [self.games[e].legal_actions() if searching[e] else [] for e in range(self.E)]
         to_play = [self.games[e].to_play() for e in range(self.E)]
-        self.engine.search(self.model, stacked, legal, to_play, True)
+        self.engine.search(self.model, stacked, legal, to_play, True)     # (an empty legal set = env not searched)
         temps = numpy.array([
             temperature if not temperature_threshold
             or len(self.histories[e].action_history) < temperature_threshold else 0
@@ -641,10 +653,14 @@ class BatchedSelfPlay(ManyEnvLoop):
         child_visits, root_values = self.engine.search_statistics()
         for e in range(self.E):
             gh = self.histories[e]
-            action = int(actions[e])
+            if searching[e]:
+                action = int(actions[e])
+                gh.child_visits.append([float(v) if a in legal[e] else 0 for a, v in enumerate(child_visits[e])])
+                gh.root_values.append(float(root_values[e]))
+            else:
+                action = self._opponent_action(e, opponent)
+                gh.root_values.append(None)
             observation, reward, done = self.games[e].step(action)
-            gh.child_visits.append([float(v) if a in legal[e] else 0 for a, v in enumerate(child_visits[e])])
-            gh.root_values.append(float(root_values[e]))
             gh.action_history.append(action)
             gh.observation_history.append(observation)
             gh.reward_history.append(reward)
@@ -656,6 +672,27 @@ class BatchedSelfPlay(ManyEnvLoop):
                     on_game(e, gh)
                 self._restart(e)
         self.moves_played += self.E
+
+    def _opponent_action(self, e, opponent):
+        """select_opponent_action (self_play.py:189-221) for env e.  The reference's opponents draw from numpy's GLOBAL
+        generator, which in a reference worker is also the search's stream (expert agents start from a random legal move:
+        games/tictactoe.py:307-312, games/connect4.py:306-343): env e's stream is lent to numpy for the call and handed
+        back to the engine afterwards (host mirror and device copy move together)."""
+        game = self.games[e]
+        saved = numpy.random.get_state()
+        numpy.random.set_state(self.engine.get_rng_state(e))
+        try:
+            if opponent == "expert":
+                action = game.expert_agent()
+            else:
+                legal = game.legal_actions()
+                assert legal, f"Legal actions should not be an empty array. Got {legal}."
+                assert set(legal).issubset(set(self.config.action_space)), "Legal actions should be a subset of the action space."
+                action = numpy.random.choice(legal)
+            self.engine.set_rng_state(e, numpy.random.get_state())
+        finally:
+            numpy.random.set_state(saved)
+        return int(action)
 
     def close(self):
         for g in self.games:
@@ -869,10 +906,16 @@ class DeviceSelfPlay(ManyEnvLoop):
         self.step_begin(on_game, on_games)
         self.step_end(temperature, temperature_threshold, on_game, on_games)
 
+    def _no_opponent(self):
+        if getattr(self, "_opponent", ("self", 0))[0] != "self":
+            raise NotImplementedError("device-resident envs play \"self\" in test mode; BatchedSelfPlay (host Game "
+                                      "plugins) plays expert / random opponents")
+
     def step_begin(self, on_game=None, on_games=None):
         """First half of step(): queue the search of every env's current position on the engine's stream and return
         (the GPU works; `step_end` waits).  Two actors on streams of their own alternate their halves
         (PipelinedDeviceSelfPlay): one's host work runs under the other's search."""
+        self._no_opponent()
         self.flush(on_game, on_games)      # first: the unfiled batch holds views of the download ring
         self._drop_batch()
         cur = self._cur
@@ -1066,6 +1109,7 @@ class DeviceSelfPlay(ManyEnvLoop):
         device_inputs = (not getattr(self.envs, "constant_legal_actions", False) or self.engine._fc_model is None
                          or bool(temperature_threshold))
         batchable = (moves_per_pass is not None and self.config.max_moves >= self.envs.max_episode_steps
+                     and getattr(self, "_opponent", ("self", 0))[0] == "self"
                      and (temperature == 0 or _native.exact_inverse_temperature(temperature))
                      # (a device-input batch draws its exploration noise on the GPU: the legacy gamma sampler for shapes <= 1)
                      and (not device_inputs or 0.0 < float(self.config.root_dirichlet_alpha) <= 1.0))
@@ -1196,6 +1240,7 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
         prefetch=False leaves no search queued behind (the next call then starts them): what a caller wants before it
         changes the weights, so that no move is searched with the weights of the move before."""
         for g, actor in enumerate(self.actors):
+            actor._opponent = getattr(self, "_opponent", ("self", 0))
             if not self._started[g]:
                 with torch.cuda.stream(self.streams[g]):
                     actor.step_begin(*self._callbacks(g, on_game, on_games))

@@ -275,3 +275,84 @@ def test_search_with_overflowing_activations_runs_on_the_fallback(pkg, monkeypat
     for (v_a, r_a), (v_b, r_b) in zip(results["split"], results["fp32"]):
         assert np.isfinite(r_a).all()
         assert np.array_equal(v_a, v_b) and np.array_equal(r_a, r_b)
+
+
+@pytest.mark.parametrize("game,batch", [("tictactoe", 5), ("tictactoe", 130), ("tictactoe", 1000), ("tictactoe", 16384),
+                                        ("atari84", 3), ("atari84", 130), ("atari84", 1001), ("atari84", 16384)])
+def test_board_column_tower_is_bit_identical_to_the_row_tile_tower(pkg, monkeypatch, game, batch):
+    """board_tower_cols_kernel / board_tower_patch_kernel (round 3: a wavefront owns whole boards -- 16 3 x 3 boards, or 4
+    6 x 6 boards as 16 patches --, positions are the MFMA tiles, no barrier between layers, the layer's output replaces its
+    input in LDS in place) against board_tower_kernel: the same k-ordered chains (minus exact zero terms on 3 x 3 boards),
+    the same epilogue -- every export equal bit for bit, for the tensor input and for the input gathered from a
+    hidden-state pool, ragged last wavefronts included."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    native = importlib.import_module("muzero-hypermodel_amd._native")
+    from parity_helpers import synthetic_model
+    if game == "atari84":
+        config = importlib.import_module("muzero-hypermodel_amd.games.breakout").atari84_config()
+        side, A = 6, 4
+    else:
+        config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+        side, A = 3, 9
+    hidden = 16 * side * side
+    model, _ = synthetic_model(models, config, "cuda")
+    g = torch.Generator().manual_seed(batch)
+    state = torch.rand((batch, 16, side, side), generator=g).cuda()
+    state[::7] = 0.0                                              # flat planes: the rescale's span + 1e-5 branch
+    action = torch.randint(0, A, (batch, 1), generator=g).cuda()
+    outs = {}
+    with torch.no_grad():
+        planes = models.state_action_planes(state, action, A)
+        # gathered form: a pool of 3 slabs whose rows are picked by a parent index per env
+        pool = torch.rand((3, batch, hidden), generator=g).cuda()
+        parent = torch.randint(0, 3, (batch,), generator=g, dtype=torch.int32).cuda()
+        gather = native.MzTowerGather(pool.data_ptr(), parent.data_ptr(), action.data_ptr(), batch, hidden, float(A))
+        for mode in ("off", "on"):
+            monkeypatch.setenv("MZ_TOWER_COLS", mode)
+            a = model._recurrent_tower(planes, None)
+            b = model._recurrent_tower(None, None, gather=gather, shape=(batch, 17, side, side), device=state.device)
+            assert a is not None and b is not None
+            outs[mode] = [t.clone() for t in a + b]
+    for x, y in zip(outs["off"], outs["on"]):
+        assert torch.isfinite(y).all()
+        assert torch.equal(x, y)
+    # and it is the gathered rows it read: the tensor form on the gathered tensor gives the same
+    with torch.no_grad():
+        rows = pool[parent.long(), torch.arange(batch, device="cuda")].view(batch, 16, side, side)
+        c = model._recurrent_tower(models.state_action_planes(rows, action, A), None)
+    for x, y in zip(c, outs["on"][3:]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("batch", [7, 130, 4099])
+def test_heads_inside_the_tower_launch_are_bit_identical(pkg, monkeypatch, batch):
+    """mzmcts_board_tower_heads (opt-in, MZ_TOWER_HEADS=on): reward / value / policy heads computed in the tower launch from the activations in LDS
+    (TicTacToe: the reward head on the raw dynamics output in mid-tower, value and policy on the last layer) return the
+    logits of the two-launch form (tower exports + conv_head_mfma_kernel) bit for bit, and the same next state -- for the
+    tensor input and the pool-gathered input."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    native = importlib.import_module("muzero-hypermodel_amd._native")
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda")
+    g = torch.Generator().manual_seed(100 + batch)
+    state = torch.rand((batch, 16, 3, 3), generator=g).cuda()
+    action = torch.randint(0, 9, (batch, 1), generator=g).cuda()
+    pool = torch.rand((2, batch, 144), generator=g).cuda()
+    parent = torch.randint(0, 2, (batch,), generator=g, dtype=torch.int32).cuda()
+    gather = native.MzTowerGather(pool.data_ptr(), parent.data_ptr(), action.data_ptr(), batch, 144, 9.0)
+    results = {}
+    with torch.no_grad():
+        planes = models.state_action_planes(state, action, 9)
+        for mode in ("off", "on"):
+            monkeypatch.setenv("MZ_TOWER_HEADS", mode)
+            if mode == "on":
+                assert model._recurrent_fused(planes, None) is not None      # the fused launch is really taken
+            out_a, out_b = torch.empty_like(state), torch.empty_like(state)
+            a = model.recurrent_inference_from_planes(planes, out_state=out_a)
+            b = model.recurrent_inference_from_pool(gather, batch, out_state=out_b)
+            results[mode] = [t.clone() for t in a + b]
+    names = ("value", "reward", "policy", "state") * 2
+    for x, y, what in zip(results["off"], results["on"], names):
+        assert torch.isfinite(y).all(), what
+        assert torch.equal(x, y), (what, float((x - y).abs().max()))

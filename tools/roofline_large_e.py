@@ -69,6 +69,22 @@ if prof["step_launches"]:
     per = b["select"] + b["expand_backup"]
     out["kernels"]["expand_backup_select"] = {"avg_us": us, "launches": prof["step_launches"], "algorithmic_bytes_per_launch": per * E,
                                               "achieved_GBs": per * E / (us * 1e-6) / 1e9, "frac_of_8TBs": per * E / (us * 1e-6) / 8e12}
+# The same kernels against what the memory system sustains for their ACCESS PATTERN (stand-alone measurement,
+# tools/record_size_ceiling.hip -> profiles/r02_record_size_ceiling.jsonl: ~50 G random 128-byte line reads / s, ~20 G random
+# line read-modify-writes / s, whatever part of a line a request uses): requests per launch are estimated from the tree
+# shape -- select: per tree the lines of its descent (0.65 per level with the first-expanded child co-located, measured on
+# the CartPole traces) + hidden-state row + path / control lines; expand_backup: the distinct lines of the path it updates.
+READ_LINES_PER_S, RMW_LINES_PER_S = 50e9, 20e9
+sel, exb = out["kernels"]["select"], out["kernels"]["expand_backup"]
+lines_per_level = 0.65 if A <= 2 else float(-(-32 * A // 128))
+sel_requests = E * (d * lines_per_level + 3.0)
+exb_requests = E * ((d + 1) * (0.65 if A <= 2 else 1.0))
+sel["request_model"] = {"random_line_reads_per_launch": sel_requests, "ceiling_lines_per_s": READ_LINES_PER_S,
+                        "time_at_ceiling_us": 1e6 * sel_requests / READ_LINES_PER_S,
+                        "frac_of_request_rate_ceiling": (sel_requests / READ_LINES_PER_S) / (sel["avg_us"] * 1e-6)}
+exb["request_model"] = {"random_line_read_modify_writes_per_launch": exb_requests, "ceiling_lines_per_s": RMW_LINES_PER_S,
+                        "time_at_ceiling_us": 1e6 * exb_requests / RMW_LINES_PER_S,
+                        "frac_of_request_rate_ceiling": (exb_requests / RMW_LINES_PER_S) / (exb["avg_us"] * 1e-6)}
 out["tree_sims_per_s_kernels_only"] = E / ((out["kernels"]["select"]["avg_us"] + out["kernels"]["expand_backup"]["avg_us"]) * 1e-6)
 print(json.dumps(out))
 engine.close()

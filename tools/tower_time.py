@@ -1,21 +1,42 @@
-import importlib, os, sys, torch
-sys.path[:0]=[os.environ.get("GRAFT_REPO_ROOT","."), os.path.join(os.environ.get("GRAFT_REPO_ROOT","."),"tests")]
+"""Time of one recurrent-inference tower launch (all 3x3 convolutions of the dynamics and prediction networks) for a
+game's network at a given batch, from a hipGraph of 10 launches; environment variables select kernel variants
+(MZ_TOWER_COLS=off: the row-tile kernel for 3x3 boards; MZ_BOARD_CONV_PRECISION=fp32; MZ_SPLIT_FALLBACK=off).
+
+    python tools/tower_time.py [game=tictactoe] [batch=65536]        -> one JSON line"""
+import importlib, json, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 from parity_helpers import synthetic_model
+game = sys.argv[1] if len(sys.argv) > 1 else "tictactoe"
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 models = importlib.import_module("muzero-hypermodel_amd.models")
-config = importlib.import_module("muzero-hypermodel_amd.games.connect4").MuZeroConfig()
-model,_ = synthetic_model(models, config, "cuda")
-b=1024
-state=torch.rand(b,64,6,7,device="cuda"); action=torch.randint(0,7,(b,1),device="cuda")
-planes=models.state_action_planes(state,action,7)
+engine = importlib.import_module("muzero-hypermodel_amd.engine")
+if game == "atari84":
+    config = importlib.import_module("muzero-hypermodel_amd.games.breakout").atari84_config()
+else:
+    config = importlib.import_module(f"muzero-hypermodel_amd.games.{game}").MuZeroConfig()
+model, _ = synthetic_model(models, config, "cuda")
+c, h, w = engine.hidden_state_shape(config)
+A = len(config.action_space)
+state = torch.rand(b, c, h, w, device="cuda")
+action = torch.randint(0, A, (b, 1), device="cuda")
+planes = models.state_action_planes(state, action, A)
 with torch.no_grad():
-    for _ in range(3): model._recurrent_tower(planes,None)
+    for _ in range(3):
+        assert model._recurrent_tower(planes, None) is not None
     torch.cuda.synchronize()
-    g=torch.cuda.CUDAGraph()
+    g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(10): model._recurrent_tower(planes,None)
+        for _ in range(10):
+            model._recurrent_tower(planes, None)
     g.replay(); torch.cuda.synchronize()
-    a,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-    a.record(); 
-    for _ in range(5): g.replay()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        g.replay()
     e.record(); torch.cuda.synchronize()
-    print("MZ_TOWER_DEBUG", os.environ.get("MZ_TOWER_DEBUG"), "tower us", 1e3*a.elapsed_time(e)/50)
+us = 1e3 * a.elapsed_time(e) / 50
+layers = 1 + 4 * config.blocks
+flops = 2 * 9 * h * w * c * (c + 1 + (layers - 1) * c) * b          # direct-convolution count, every tap at every position
+print(json.dumps({"game": game, "batch": b, "tower_us": us, "algorithmic_TFLOPs": flops / us / 1e6,
+                  "env": {k: os.environ.get(k) for k in ("MZ_TOWER_COLS", "MZ_BOARD_CONV_PRECISION", "MZ_SPLIT_FALLBACK") if os.environ.get(k)}}))
