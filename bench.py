@@ -806,10 +806,21 @@ def network_leg(wl, device, repeats=20):
                 executed = alg * (3 if split else 1)
                 peak = F16_MATRIX_PEAK_TFLOPS if split else FP32_MATRIX_PEAK_TFLOPS
                 tf = executed / (us * 1e-6) / 1e12
+                _, bh, bw = engine.state_shape
+                cols = (not split and wl.config.channels == 16 and (bh, bw) in ((3, 3), (6, 6))
+                        and os.environ.get("MZ_TOWER_COLS", "on") != "off")
+                kernel = ("mz::board_tower_split_kernel" if split else
+                          ("mz::board_tower_cols_kernel" if (bh, bw) == (3, 3) else "mz::board_tower_patch_kernel") if cols else
+                          "mz::board_tower_kernel")
+                if cols and (bh, bw) == (3, 3):
+                    # the board-column kernel skips the products with padding zeros (taps outside a 3 x 3 board): 49 of the
+                    # 81 (position, tap) pairs are multiplied; `achieved` stays the algorithmic count of a padded convolution
+                    executed = alg * 49.0 / 81.0
                 out["board_tower"] = {
-                    "bound": "mfma", "what": "mz::board_tower_split_kernel" if split else "mz::board_tower_kernel",
+                    "bound": "mfma", "what": kernel,
                     "avg_us": us, "launches": repeats, "flops_per_launch": executed, "algorithmic_flops_per_launch": alg,
                     "achieved_TFLOPs": tf, "peak_TFLOPs": peak, "frac_of_matrix_peak": tf / peak,
+                    "executed_TFLOPs": executed / (us * 1e-6) / 1e12,
                     "precision": "two fp16 halves per operand, three products, fp32 accumulate" if split else "fp32 MFMA",
                     "fp32_equivalent_TFLOPs": alg / (us * 1e-6) / 1e12}
         else:
