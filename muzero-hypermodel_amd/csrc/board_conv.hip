@@ -1215,6 +1215,118 @@ static int launch_board_tower_patch66(const float* x, int batch, int cin0, const
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// The heads of a 16-channel 3 x 3 network as a launch of their own in the board-column shape (round 3): a wavefront takes
+// 16 boards, brings their NCHW planes into LDS as [board][position][channel] with coalesced loads, and runs cols_head_* --
+// conv_head_mfma_kernel's arithmetic operation for operation, so the logits are that kernel's bit for bit
+// (tests/test_gpu_net.py) -- with the Linear-1 weights staged once per workgroup.  One head reading tensor x0 (the reward
+// head on the raw dynamics output) and up to two reading x1 (value and policy on the prediction features): the pattern
+// of recurrent_inference (models.py:467-480, 500-522).
+// -------------------------------------------------------------------------------------------------------------------
+struct HeadsColsArgs {
+    const float* x0;          // or null
+    TowerHead single;
+    const float* x1;          // or null
+    TowerHead pair0, pair1;
+    int32_t n_pair;
+};
+
+__global__ __launch_bounds__(64 * kColWaves) void board_heads_cols_kernel(HeadsColsArgs a, int batch) {
+    constexpr int P = 9, ROW = 16 * P, FILL = 16 * ROW / 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* w1_lds = lds + kColWaves * kColWaveFloats;
+    if (a.x0) cols_stage_head(a.single.d, w1_lds, P, tid, 64 * kColWaves);
+    if (a.x1 && a.n_pair > 0) cols_stage_head(a.pair0.d, w1_lds + kColHeadW1Floats, P, tid, 64 * kColWaves);
+    if (a.x1 && a.n_pair > 1) cols_stage_head(a.pair1.d, w1_lds + 2 * kColHeadW1Floats, P, tid, 64 * kColWaves);
+    __syncthreads();
+    const int b0 = (blockIdx.x * kColWaves + wave) * 16;
+    const int n_boards = min(16, batch - b0);
+    if (n_boards <= 0) return;
+    float* xw = lds + wave * kColWaveFloats;
+    float* ys = xw;
+    float* hs = xw + 16 * (16 * P + 1);
+    auto fill = [&](const float* x) {                               // 16 boards' planes, contiguous in global memory
+        float v[FILL];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            v[it] = idx < n_boards * ROW ? x[static_cast<size_t>(b0) * ROW + idx] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int idx = lane + 64 * it;
+            const int q = idx / ROW, cp = idx - q * ROW;
+            const int c = cp / P, p0 = cp - c * P;
+            xw[q * kColBoardStride + p0 * 16 + c] = v[it];
+        }
+    };
+    if (a.x0) {
+        ColsHeadConv c0;
+        ColsHeadFc<P> f0;
+        cols_head_load_conv(a.single.d, lane, c0);
+        cols_head_load_fc<P>(a.single.d, w1_lds, lane, f0);
+        fill(a.x0);
+        cols_wave_sync();
+        f32x4 y0[P];
+        cols_head_conv<P>(c0, xw, lane, y0);
+        cols_wave_sync();
+        cols_head_finish<P>(a.single, c0, f0, y0, ys, hs, b0, n_boards, lane);
+    }
+    if (a.x1 && a.n_pair > 0) {
+        ColsHeadConv c0, c1;
+        ColsHeadFc<P> f0, f1;
+        cols_head_load_conv(a.pair0.d, lane, c0);
+        if (a.n_pair > 1) cols_head_load_conv(a.pair1.d, lane, c1);
+        cols_head_load_fc<P>(a.pair0.d, w1_lds + kColHeadW1Floats, lane, f0);
+        if (a.n_pair > 1) cols_head_load_fc<P>(a.pair1.d, w1_lds + 2 * kColHeadW1Floats, lane, f1);
+        fill(a.x1);
+        cols_wave_sync();
+        f32x4 y0[P], y1[P];
+        cols_head_conv<P>(c0, xw, lane, y0);
+        if (a.n_pair > 1) cols_head_conv<P>(c1, xw, lane, y1);
+        cols_wave_sync();
+        cols_head_finish<P>(a.pair0, c0, f0, y0, ys, hs, b0, n_boards, lane);
+        if (a.n_pair > 1) cols_head_finish<P>(a.pair1, c1, f1, y1, ys, hs, b0, n_boards, lane);
+    }
+}
+
+// mzmcts_conv_heads_multi's fast path (net_kernels.hip calls it first): MZMCTS_ERR_INVALID = this launch does not cover
+// the shapes / the pattern of inputs, the caller takes conv_head_mfma_kernel.
+int launch_board_heads_cols(const float* const* xs, const mzmcts_head_desc* heads, int n_heads, float* const* outs,
+                            int64_t batch, hipStream_t stream) {
+    const char* env = std::getenv("MZ_HEADS_COLS");
+    if (env && std::string(env) == "off") return MZMCTS_ERR_INVALID;
+    if (n_heads < 1 || n_heads > 3 || batch > 0x3fffffff) return MZMCTS_ERR_INVALID;
+    for (int h = 0; h < n_heads; ++h) {
+        const mzmcts_head_desc& d = heads[h];
+        if (!xs[h] || !outs[h] || !d.conv_w || !d.conv_b || !d.fc1_w || !d.fc1_b || !d.fc2_w || !d.fc2_b || d.channels != 16 ||
+            d.plane != 9 || d.reduced < 1 || d.reduced > 16 || d.hidden < 1 || d.hidden > 16 || d.outputs < 1 || d.outputs > 32)
+            return MZMCTS_ERR_INVALID;
+    }
+    HeadsColsArgs a{};
+    auto head_of = [&](int h) { return TowerHead{heads[h], outs[h], 0, 0}; };
+    if (n_heads == 1) {
+        a.x0 = xs[0], a.single = head_of(0);
+    } else if (n_heads == 2) {
+        if (xs[0] == xs[1]) a.x1 = xs[0], a.pair0 = head_of(0), a.pair1 = head_of(1), a.n_pair = 2;
+        else a.x0 = xs[0], a.single = head_of(0), a.x1 = xs[1], a.pair0 = head_of(1), a.n_pair = 1;
+    } else {
+        if (xs[1] == xs[2] && xs[0] != xs[1]) a.x0 = xs[0], a.single = head_of(0), a.x1 = xs[1], a.pair0 = head_of(1), a.pair1 = head_of(2), a.n_pair = 2;
+        else if (xs[0] == xs[1] && xs[2] != xs[0]) a.x0 = xs[2], a.single = head_of(2), a.x1 = xs[0], a.pair0 = head_of(0), a.pair1 = head_of(1), a.n_pair = 2;
+        else return MZMCTS_ERR_INVALID;
+    }
+    if (batch == 0) return MZMCTS_OK;
+    const size_t lds = sizeof(float) * (static_cast<size_t>(kColWaves) * kColWaveFloats + 3 * kColHeadW1Floats);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(board_heads_cols_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+        return MZMCTS_ERR_HIP;
+    const int per_group = 16 * kColWaves;
+    board_heads_cols_kernel<<<dim3(static_cast<unsigned>((batch + per_group - 1) / per_group)), dim3(64 * kColWaves), lds, stream>>>(
+        a, static_cast<int>(batch));
+    return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
+}
+
 static bool tower_cols_applies(int channels, int height, int width, int cin0, const TowerArgs& args) {
     const char* env = std::getenv("MZ_TOWER_COLS");              // "off": the row-tile kernel (A/B runs, the equality test)
     const bool off = env && std::string(env) == "off";

@@ -574,12 +574,22 @@ extern "C" int mzmcts_unit_rescale(const float* x, float* out, int64_t rows, int
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
+namespace mz {
+// board_conv.hip: the heads of 16-channel 3 x 3 networks in the board-column shape (same bits as conv_head_mfma_kernel)
+int launch_board_heads_cols(const float* const* xs, const mzmcts_head_desc* heads, int n_heads, float* const* outs,
+                            int64_t batch, hipStream_t stream);
+}
+
 extern "C" int mzmcts_conv_heads_multi(const float* const* xs, const mzmcts_head_desc* heads, int32_t n_heads,
                                        float* const* outs, int64_t batch, void* stream_) {
     if (!xs || !heads || !outs || n_heads < 1 || n_heads > mz::kMaxHeads || batch < 0 || batch > 0x7fffffff)
         return MZMCTS_ERR_INVALID;
     for (int h = 0; h < n_heads; ++h)
         if (!xs[h] || (reinterpret_cast<uintptr_t>(xs[h]) & 15u)) return MZMCTS_ERR_INVALID;
+    {
+        const int rc = mz::launch_board_heads_cols(xs, heads, n_heads, outs, batch, static_cast<hipStream_t>(stream_));
+        if (rc != MZMCTS_ERR_INVALID) return rc;
+    }
     static const bool use_mfma = std::getenv("MZ_HEADS_WAVE_PER_SAMPLE") == nullptr;
     bool mfma = use_mfma;      // (any batch: a sample's logits do not depend on how many samples share its launch)
     for (int h = 0; h < n_heads && mfma; ++h) mfma = mz::mfma_head_ok(heads[h]);

@@ -1065,8 +1065,15 @@ class DeviceSelfPlay(ManyEnvLoop):
         eng.moves_prepare_device(n_moves, envs.legal, envs.num_legal, envs.to_play, temperature, True)
         if temperature_threshold:
             eng.moves_temperature_threshold(temperature_threshold, self._len)
-        self._dev_batch = dict(n_moves=n_moves, ring=self._move_ring(n_moves), obs_in=self._cur["obs_dev"],
-                               threshold=temperature_threshold)
+        ring = self._move_ring(n_moves)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        # the env outputs of a move (reward, done, the observations the history rows need) go to pinned host memory on a
+        # copy stream as soon as the move's env kernel has run: the downloads ride under the batch's remaining searches
+        pinned = ring["pinned"][ring["flip"]]
+        ring["flip"] ^= 1
+        self._dev_batch = dict(n_moves=n_moves, ring=ring, obs_in=self._cur["obs_dev"], threshold=temperature_threshold,
+                               pinned=pinned)
 
     def _device_batch_move(self, m):
         b, eng, envs = self._dev_batch, self.engine, self.envs
@@ -1079,6 +1086,12 @@ class DeviceSelfPlay(ManyEnvLoop):
             eng.moves_enqueue_lockstep(self.model, b["obs_in"])
         b["obs_in"] = envs.advance(eng.moves_actions(m), ring["reward"][m], ring["done"][m], ring["obs_after"][m],
                                    ring["obs_next"][m])
+        ran = torch.cuda.Event()
+        ran.record(torch.cuda.current_stream(self.device))
+        self._copy_stream.wait_event(ran)
+        with torch.cuda.stream(self._copy_stream):
+            for k in ("reward", "done", "obs_after", "obs_next"):
+                b["pinned"][k][m].copy_(ring[k][m], non_blocking=True)
 
     def _device_batch_end(self, on_game, on_games):
         b, eng, envs = self._dev_batch, self.engine, self.envs
@@ -1087,11 +1100,9 @@ class DeviceSelfPlay(ManyEnvLoop):
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
         out = eng.moves_collect()
         inputs = eng.moves_inputs(n_moves)
-        pinned = ring["pinned"][ring["flip"]]
-        ring["flip"] ^= 1
-        for k in ("reward", "done", "obs_after", "obs_next"):
-            pinned[k][:n_moves].copy_(ring[k][:n_moves], non_blocking=True)
-        last_to_play = envs.to_play.cpu().numpy()        # (waits for the copies queued before it)
+        pinned = b["pinned"]
+        last_to_play = envs.to_play.cpu().numpy()
+        self._copy_stream.synchronize()                  # (the last move's downloads)
         host = {k: pinned[k][:n_moves].numpy() for k in ("reward", "done", "obs_after", "obs_next")}
         two_players = len(self.config.players) > 1
         to_play = inputs["to_play"]

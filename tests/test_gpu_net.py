@@ -307,3 +307,35 @@ def test_towers_gathering_from_the_pool_equal_the_planes_form(pkg, game, split, 
         got = model.recurrent_inference_from_pool(gather, E, out_state=got_state)
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("batch", [3, 16, 130, 4099, 65536])
+def test_board_column_heads_are_bit_identical_to_the_mfma_heads(pkg, monkeypatch, batch):
+    """board_heads_cols_kernel (round 3: the TicTacToe heads with a wavefront per 16 boards, planes through LDS, Linear-1
+    weights staged once per workgroup) against conv_head_mfma_kernel: reward head on one tensor, value and policy heads on
+    another -- the same chains of fused multiply-adds, the same logits bit for bit; also one and two heads on one tensor."""
+    import importlib
+    import torch
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    from parity_helpers import synthetic_model
+    config = importlib.import_module("muzero-hypermodel_amd.games.tictactoe").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda")
+    dyn, pred = model.dynamics_network.module, model.prediction_network.module
+    g = torch.Generator().manual_seed(batch)
+    raw = (torch.randn((batch, 16, 3, 3), generator=g) * 2).cuda()
+    features = torch.rand((batch, 16, 3, 3), generator=g).cuda()
+    trios = [(raw, (dyn.conv1x1_reward, dyn.fc, dyn.block_output_size_reward)),
+             (features, (pred.conv1x1_value, pred.fc_value, pred.block_output_size_value)),
+             (features, (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy))]
+    out = {}
+    with torch.no_grad():
+        for mode in ("off", "on"):
+            monkeypatch.setenv("MZ_HEADS_COLS", mode)
+            out[mode] = [t.clone() for t in models.conv_heads_multi(trios)] + \
+                        [t.clone() for t in models.conv_heads_multi(trios[1:])] + \
+                        [t.clone() for t in models.conv_heads_multi(trios[:1])]
+        want = [fc(conv(x).reshape(-1, flat)) for x, (conv, fc, flat) in trios]
+    for a, b in zip(out["off"], out["on"]):
+        assert torch.equal(a, b)
+    for got, ref in zip(out["on"][:3], want):
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
