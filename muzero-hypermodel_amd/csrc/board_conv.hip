@@ -663,9 +663,22 @@ constexpr int kColHeadW1Floats = 16 * (16 * 9 + 1);          // LDS floats of on
 // Linear-1 weights of a head -> LDS [unit][R P + 1] by the whole workgroup (rows beyond `hidden` are never read)
 __device__ __forceinline__ void cols_stage_head(const mzmcts_head_desc& d, float* dst, int P, int tid, int nthreads) {
     const int RP = d.reduced * P, n = d.hidden * RP;
-    for (int idx = tid; idx < n; idx += nthreads) {
-        const int u = idx / RP, k = idx - u * RP;
-        dst[u * (RP + 1) + k] = d.fc1_w[idx];
+    constexpr int kInFlight = 8;                                    // (the staging is latency: independent loads per thread)
+    for (int base = tid; base < n; base += nthreads * kInFlight) {
+        float v[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int idx = base + u * nthreads;
+            v[u] = idx < n ? d.fc1_w[idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx < n) {
+                const int row = idx / RP;
+                dst[row * (RP + 1) + idx - row * RP] = v[u];
+            }
+        }
     }
 }
 
@@ -1224,21 +1237,22 @@ static int launch_board_tower_patch66(const float* x, int batch, int cin0, const
 // of recurrent_inference (models.py:467-480, 500-522).
 // -------------------------------------------------------------------------------------------------------------------
 struct HeadsColsArgs {
-    const float* x0;          // or null
-    TowerHead single;
-    const float* x1;          // or null
-    TowerHead pair0, pair1;
-    int32_t n_pair;
+    const float* x[3];
+    TowerHead head[3];
+    int32_t n;
 };
 
+// one head per workgroup (blockIdx.y): three times the wavefronts of a launch that ran a board's heads one after the
+// other, each with a third of the dependent chain (the heads are latency, not arithmetic: ~80 MFMAs per 16 boards)
 __global__ __launch_bounds__(64 * kColWaves) void board_heads_cols_kernel(HeadsColsArgs a, int batch) {
     constexpr int P = 9, ROW = 16 * P, FILL = 16 * ROW / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (static selection of the head: the argument segment is addressed with constant offsets)
+    const TowerHead hd = blockIdx.y == 0 ? a.head[0] : (blockIdx.y == 1 ? a.head[1] : a.head[2]);
+    const float* x = blockIdx.y == 0 ? a.x[0] : (blockIdx.y == 1 ? a.x[1] : a.x[2]);
     float* w1_lds = lds + kColWaves * kColWaveFloats;
-    if (a.x0) cols_stage_head(a.single.d, w1_lds, P, tid, 64 * kColWaves);
-    if (a.x1 && a.n_pair > 0) cols_stage_head(a.pair0.d, w1_lds + kColHeadW1Floats, P, tid, 64 * kColWaves);
-    if (a.x1 && a.n_pair > 1) cols_stage_head(a.pair1.d, w1_lds + 2 * kColHeadW1Floats, P, tid, 64 * kColWaves);
+    cols_stage_head(hd.d, w1_lds, P, tid, 64 * kColWaves);
     __syncthreads();
     const int b0 = (blockIdx.x * kColWaves + wave) * 16;
     const int n_boards = min(16, batch - b0);
@@ -1246,7 +1260,11 @@ __global__ __launch_bounds__(64 * kColWaves) void board_heads_cols_kernel(HeadsC
     float* xw = lds + wave * kColWaveFloats;
     float* ys = xw;
     float* hs = xw + 16 * (16 * P + 1);
-    auto fill = [&](const float* x) {                               // 16 boards' planes, contiguous in global memory
+    ColsHeadConv c0;
+    ColsHeadFc<P> f0;
+    cols_head_load_conv(hd.d, lane, c0);
+    cols_head_load_fc<P>(hd.d, w1_lds, lane, f0);
+    {                                                               // 16 boards' planes, contiguous in global memory
         float v[FILL];
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {
@@ -1260,70 +1278,39 @@ __global__ __launch_bounds__(64 * kColWaves) void board_heads_cols_kernel(HeadsC
             const int c = cp / P, p0 = cp - c * P;
             xw[q * kColBoardStride + p0 * 16 + c] = v[it];
         }
-    };
-    if (a.x0) {
-        ColsHeadConv c0;
-        ColsHeadFc<P> f0;
-        cols_head_load_conv(a.single.d, lane, c0);
-        cols_head_load_fc<P>(a.single.d, w1_lds, lane, f0);
-        fill(a.x0);
-        cols_wave_sync();
-        f32x4 y0[P];
-        cols_head_conv<P>(c0, xw, lane, y0);
-        cols_wave_sync();
-        cols_head_finish<P>(a.single, c0, f0, y0, ys, hs, b0, n_boards, lane);
     }
-    if (a.x1 && a.n_pair > 0) {
-        ColsHeadConv c0, c1;
-        ColsHeadFc<P> f0, f1;
-        cols_head_load_conv(a.pair0.d, lane, c0);
-        if (a.n_pair > 1) cols_head_load_conv(a.pair1.d, lane, c1);
-        cols_head_load_fc<P>(a.pair0.d, w1_lds + kColHeadW1Floats, lane, f0);
-        if (a.n_pair > 1) cols_head_load_fc<P>(a.pair1.d, w1_lds + 2 * kColHeadW1Floats, lane, f1);
-        fill(a.x1);
-        cols_wave_sync();
-        f32x4 y0[P], y1[P];
-        cols_head_conv<P>(c0, xw, lane, y0);
-        if (a.n_pair > 1) cols_head_conv<P>(c1, xw, lane, y1);
-        cols_wave_sync();
-        cols_head_finish<P>(a.pair0, c0, f0, y0, ys, hs, b0, n_boards, lane);
-        if (a.n_pair > 1) cols_head_finish<P>(a.pair1, c1, f1, y1, ys, hs, b0, n_boards, lane);
-    }
+    cols_wave_sync();
+    f32x4 y0[P];
+    cols_head_conv<P>(c0, xw, lane, y0);
+    cols_wave_sync();
+    cols_head_finish<P>(hd, c0, f0, y0, ys, hs, b0, n_boards, lane);
 }
 
 // mzmcts_conv_heads_multi's fast path (net_kernels.hip calls it first): MZMCTS_ERR_INVALID = this launch does not cover
-// the shapes / the pattern of inputs, the caller takes conv_head_mfma_kernel.
+// the shapes, the caller takes conv_head_mfma_kernel.
 int launch_board_heads_cols(const float* const* xs, const mzmcts_head_desc* heads, int n_heads, float* const* outs,
                             int64_t batch, hipStream_t stream) {
     const char* env = std::getenv("MZ_HEADS_COLS");
     if (env && std::string(env) == "off") return MZMCTS_ERR_INVALID;
     if (n_heads < 1 || n_heads > 3 || batch > 0x3fffffff) return MZMCTS_ERR_INVALID;
+    HeadsColsArgs a{};
+    a.n = n_heads;
     for (int h = 0; h < n_heads; ++h) {
         const mzmcts_head_desc& d = heads[h];
         if (!xs[h] || !outs[h] || !d.conv_w || !d.conv_b || !d.fc1_w || !d.fc1_b || !d.fc2_w || !d.fc2_b || d.channels != 16 ||
             d.plane != 9 || d.reduced < 1 || d.reduced > 16 || d.hidden < 1 || d.hidden > 16 || d.outputs < 1 || d.outputs > 32)
             return MZMCTS_ERR_INVALID;
-    }
-    HeadsColsArgs a{};
-    auto head_of = [&](int h) { return TowerHead{heads[h], outs[h], 0, 0}; };
-    if (n_heads == 1) {
-        a.x0 = xs[0], a.single = head_of(0);
-    } else if (n_heads == 2) {
-        if (xs[0] == xs[1]) a.x1 = xs[0], a.pair0 = head_of(0), a.pair1 = head_of(1), a.n_pair = 2;
-        else a.x0 = xs[0], a.single = head_of(0), a.x1 = xs[1], a.pair0 = head_of(1), a.n_pair = 1;
-    } else {
-        if (xs[1] == xs[2] && xs[0] != xs[1]) a.x0 = xs[0], a.single = head_of(0), a.x1 = xs[1], a.pair0 = head_of(1), a.pair1 = head_of(2), a.n_pair = 2;
-        else if (xs[0] == xs[1] && xs[2] != xs[0]) a.x0 = xs[2], a.single = head_of(2), a.x1 = xs[0], a.pair0 = head_of(0), a.pair1 = head_of(1), a.n_pair = 2;
-        else return MZMCTS_ERR_INVALID;
+        a.x[h] = xs[h];
+        a.head[h] = TowerHead{d, outs[h], 0, 0};
     }
     if (batch == 0) return MZMCTS_OK;
-    const size_t lds = sizeof(float) * (static_cast<size_t>(kColWaves) * kColWaveFloats + 3 * kColHeadW1Floats);
+    const size_t lds = sizeof(float) * (static_cast<size_t>(kColWaves) * kColWaveFloats + kColHeadW1Floats);
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(board_heads_cols_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
         return MZMCTS_ERR_HIP;
     const int per_group = 16 * kColWaves;
-    board_heads_cols_kernel<<<dim3(static_cast<unsigned>((batch + per_group - 1) / per_group)), dim3(64 * kColWaves), lds, stream>>>(
-        a, static_cast<int>(batch));
+    board_heads_cols_kernel<<<dim3(static_cast<unsigned>((batch + per_group - 1) / per_group), static_cast<unsigned>(n_heads)),
+                              dim3(64 * kColWaves), lds, stream>>>(a, static_cast<int>(batch));
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
 
