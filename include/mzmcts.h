@@ -425,12 +425,14 @@ typedef struct mzmcts_tower_layer {
     /* layer 0 only (NULL elsewhere, and NULL = off): overflow hand-over between the two forms of a 64-channel tower,
      * dev i32[mzmcts_board_tower_blocks(batch, channels, height, width) + 1].  The split tower WRITES it: gate[i] = 1 if a
      * value of block i's samples left the fp16 range (|value| * 8 >= 65504) or was not finite, else 0; gate[blocks] counts
-     * flagged blocks since the caller last cleared it.  The exact-fp32 tower READS it: only blocks with gate[i] != 0 run.
+     * flagged blocks since the caller last cleared it.  The exact-fp32 tower READS it: of its own workgroups only those
+     * holding a sample of a block with gate[i] != 0 run (its workgroups may be larger than the split launch's blocks).
      * Launched back to back on one stream (split, then fp32 with the same layers' fp32 weights and exports) the pair
      * re-computes overflowed samples at full range with no host in between -- also inside a captured hipGraph. */
     int32_t *gate;
 } mzmcts_tower_layer;
-/* Blocks (workgroups of samples) a tower launch of `batch` samples has; the same for both forms of a 64-channel tower. */
+/* Blocks (workgroups of samples) a tower launch of `batch` samples has; for a 64-channel tower: of the split launch,
+ * the unit of the overflow hand-over. */
 int64_t mzmcts_board_tower_blocks(int64_t batch, int32_t channels, int32_t height, int32_t width);
 int mzmcts_board_tower(const float *x, int64_t batch, int32_t cin0, int32_t channels, int32_t height, int32_t width,
                        const mzmcts_tower_layer *layers, int32_t n_layers, void *stream);

@@ -289,9 +289,11 @@ constexpr int kMaxTowerLayers = 16;
 struct TowerArgs {
     TowerLayer layer[kMaxTowerLayers];
     int32_t n_layers;
-    // not null: workgroup i runs only if gate[i] != 0 -- the re-run of the blocks of samples a split-precision launch
-    // flagged as overflowed (same samples per workgroup in both kernels), queued behind it with no host in between
+    // not null: a workgroup runs only if a gate entry covering one of its samples is != 0 (entry i = samples
+    // i * gate_samples .. + gate_samples - 1: the workgroups of the split-precision launch that flagged them as
+    // overflowed) -- the re-run of those samples, queued behind that launch with no host in between
     const int32_t* gate;
+    int32_t gate_samples;
 };
 
 // A reward / value / policy head computed inside a tower launch from the activations of `layer` while they are in LDS
@@ -348,9 +350,13 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    if (args.gate && args.gate[blockIdx.x] == 0) return;   // (uniform over the workgroup: before any barrier)
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
+    if (args.gate) {                                       // (uniform over the workgroup: before any barrier)
+        int flagged = 0;
+        for (int e = b0 / args.gate_samples; e <= (b0 + n_samples - 1) / args.gate_samples; ++e) flagged |= args.gate[e];
+        if (!flagged) return;
+    }
     const int buf1_at = SB * PP * cp0;                  // (offsets into lds, so that every access stays an LDS access)
     MZ_TSTAMP_DECL
 
@@ -1451,10 +1457,12 @@ struct SplitArgs {
     // not null: gate[i] = 1 if a value of workgroup i's samples left the fp16 range (or was not finite), else 0, written
     // by every launch; gate[number of workgroups] counts the flagged workgroups since it was last cleared
     int32_t* gate;
+    // != 0: the wavefront in the SIMD's even slot runs at a raised issue priority (see the kernel)
+    int32_t slot_priority;
 };
 
-template <int H, int W, int SB>
-__global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(const float* __restrict__ x, int batch, int cin0,
+template <int H, int W, int SB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void board_tower_split_kernel(const float* __restrict__ x, int batch, int cin0,
                                                                              int const_plane, uint32_t cin_load_magic,
                                                                              int cph0, int cph1, SplitArgs args,
                                                                              TowerGather gather) {
@@ -1463,10 +1471,11 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     constexpr int PP = (H + 2) * PW + 1;
     constexpr int ROWS = SB * P;
     constexpr int MT = (ROWS + 15) / 16;
-    constexpr int RG = 4;                               // row groups; wave = (column pair, row group)
+    constexpr int RG = WAVES / 2;                       // row groups; wave = (column pair, row group)
     constexpr int MTW = (MT + RG - 1) / RG;
     constexpr int COUT = 64;
-    constexpr int THREADS = 64 * kConvWaves;
+    constexpr int THREADS = 64 * WAVES;
+    static_assert(WAVES >= 2 && WAVES % 2 == 0 && THREADS >= P && THREADS >= SB, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) _Float16 hl[];   // buffer 0 [SB*PP][2][cph0] | buffer 1 [SB*PP][2][cph1] | consts
 
     const int tid = threadIdx.x;
@@ -1474,6 +1483,14 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     const int wave = tid >> 6;
     const int b0 = blockIdx.x * SB;
     const int n_samples = min(SB, batch - b0);
+    // Two workgroups share a CU (one wavefront of each per SIMD).  Left alone they fall into step -- whoever is ahead
+    // meets the other in the MFMA loop, where the one behind then runs alone at twice the rate and catches up -- and the
+    // matrix pipe idles through both epilogues.  A fixed priority by wavefront slot (HW_ID bits 3:0) breaks the symmetry:
+    // the even slot's workgroup never waits, the odd slot's multiplies while the even one is in its epilogue / barrier /
+    // export phases.
+    if (WAVES < 8 && args.slot_priority) {
+        if ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) == 0) __builtin_amdgcn_s_setprio(3);
+    }
     MZ_TSTAMP_DECL
     const int buf1_at = SB * PP * 2 * cph0;             // (offsets into hl, so that every access stays an LDS access)
     float* aconst = reinterpret_cast<float*>(hl + SB * PP * 2 * (cph0 + cph1));   // [SB] the constant plane's value
@@ -1801,7 +1818,7 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_split_kernel(cons
     MZ_TSTAMP_FLUSH;
 }
 
-template <int H, int W, int SB>
+template <int H, int W, int SB, int WAVES = kConvWaves>
 static int launch_board_tower_split(const float* x, int batch, int cin0, int const_plane, const SplitArgs& args,
                                     hipStream_t stream, const TowerGather& gather = TowerGather{}) {
     constexpr int PP = (H + 2) * (W + 1) + 1;
@@ -1812,11 +1829,11 @@ static int launch_board_tower_split(const float* x, int batch, int cin0, int con
     }
     const size_t lds = sizeof(_Float16) * static_cast<size_t>(SB) * PP * 2 * (cph0 + cph1) + (sizeof(float) + sizeof(float*)) * SB;
     if (lds > 160 * 1024) return MZMCTS_ERR_INVALID;
-    auto kernel = board_tower_split_kernel<H, W, SB>;
+    auto kernel = board_tower_split_kernel<H, W, SB, WAVES>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                static_cast<int>(lds)) != hipSuccess)
         return MZMCTS_ERR_HIP;
-    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
+    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * WAVES);
     const int cin_load = cin0 - const_plane;
     kernel<<<grid, block, lds, stream>>>(x, batch, cin0, const_plane, 0xFFFFFFFFu / static_cast<uint32_t>(cin_load) + 1u, cph0,
                                          cph1, args, gather);
@@ -1893,6 +1910,22 @@ extern "C" int mzmcts_board_conv3x3(const float* x, const float* packed, const f
     return mz::launch_board_conv<1, 3, 3, 32>(x, packed, scale, shift, residual, out, b, cin, relu, stream);
 }
 
+// Boards per workgroup of the split-precision 64-channel tower.  6 x 7: TWO boards on FOUR wavefronts (84 rows = 6 tiles,
+// three per wavefront, as with 4 boards on 8), because half the LDS lets two workgroups share a CU: one's fill / epilogue
+// / barrier / export phases (55 % of a workgroup's life, profiles/r02_tower_phase_stamps.jsonl) run under the other's MFMAs.
+// MZ_SPLIT_BOARDS=4|2|1 selects the shape (A/B measurements).
+static int split_block_samples(int32_t height, int32_t width) {
+    if (height == 6 && width == 7) {
+        static const int chosen = [] {
+            const char* env = std::getenv("MZ_SPLIT_BOARDS");
+            const int v = env ? std::atoi(env) : 2;
+            return (v == 4 || v == 2 || v == 1) ? v : 2;
+        }();
+        return chosen;
+    }
+    return height == 3 ? 16 : 4;
+}
+
 static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64_t batch, int32_t cin0, int32_t channels,
                             int32_t height, int32_t width, const mzmcts_tower_layer* layers, int32_t n_layers, void* stream_,
                             const mzmcts_tower_head* heads = nullptr, int32_t n_heads = 0) {
@@ -1923,6 +1956,7 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     }
     args.gate = layers[0].gate;
     if (args.gate && channels != 64) return MZMCTS_ERR_INVALID;   // (the hand-over exists between the two 64-channel forms)
+    args.gate_samples = split_block_samples(height, width);
     // heads inside the launch: the 3 x 3 board-column kernel only -- decided before anything is launched
     if (n_heads > 0 && !(height == 3 && width == 3 && mz::tower_cols_applies(channels, height, width, cin0, args)))
         return MZMCTS_ERR_INVALID;
@@ -1962,10 +1996,11 @@ static int board_tower_impl(const float* x, const mz::TowerGather& gather, int64
     return mz::launch_board_tower<1, 3, 3, 16>(x, b, cin0, args, stream, gather);
 }
 
-// samples per workgroup of the tower launches of a given shape (the table board_tower_impl / board_tower_split_impl use)
+// samples per workgroup of the tower launches of a given shape (the table board_tower_impl / board_tower_split_impl use;
+// for 64 channels: of the SPLIT launch, whose workgroups are the units of the overflow hand-over)
 static int tower_block_samples(int64_t batch, int32_t channels, int32_t height, int32_t width) {
     const bool many = batch >= 16384;
-    if (height == 6 && width == 7) return channels == 64 ? 4 : 0;       // (16 channels: depends on the input's parity too)
+    if (height == 6 && width == 7) return channels == 64 ? split_block_samples(height, width) : 0;   // (16 channels: depends on the input's parity too)
     if (height == 6 && width == 6) return channels == 64 ? 4 : (many ? 3 : 4);
     return channels == 64 ? 16 : (many ? 14 : 16);
 }
@@ -2037,13 +2072,25 @@ static int board_tower_split_impl(const float* x, const mz::TowerGather& gather,
                                        cin_conv, d.relu, d.skip, 0};
     }
     args.gate = layers[0].gate;
+    {
+        static const int slot_priority = [] {
+            const char* env = std::getenv("MZ_SPLIT_PRIORITY");
+            return (env && std::string(env) == "off") ? 0 : 1;
+        }();
+        args.slot_priority = slot_priority;
+    }
     if (batch == 0) return MZMCTS_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int b = static_cast<int>(batch);
     // (4 boards per workgroup: 3 fill the MFMA rounds better -- 126 rows = 8 tiles -- and 2 let two workgroups share a
     // CU, but both measured slower at 4096 Connect4 boards: 700 / 744 / 900 us per launch for 4 / 3 / 2; again after the
     // packed epilogue, 8192 boards with heads: 1289 us for 4, 1366 us for 3)
-    if (height == 6 && width == 7) return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream, gather);
+    if (height == 6 && width == 7) {
+        const int sb = split_block_samples(height, width);
+        if (sb == 2) return mz::launch_board_tower_split<6, 7, 2, 4>(x, b, cin0, const_plane, args, stream, gather);
+        if (sb == 1) return mz::launch_board_tower_split<6, 7, 1, 2>(x, b, cin0, const_plane, args, stream, gather);
+        return mz::launch_board_tower_split<6, 7, 4>(x, b, cin0, const_plane, args, stream, gather);
+    }
     if (height == 6 && width == 6) return mz::launch_board_tower_split<6, 6, 4>(x, b, cin0, const_plane, args, stream, gather);
     return mz::launch_board_tower_split<3, 3, 16>(x, b, cin0, const_plane, args, stream, gather);
 }

@@ -38,9 +38,9 @@ with torch.no_grad():
         model.recurrent_inference_from_planes(planes, out_state=out_state)
     torch.cuda.synchronize()
     lib.mzmcts_tower_stamps(stamps, 1)
-per_wg = {"tictactoe": 14, "connect4": 4}.get(game, 4)    # boards per workgroup (board_conv.hip's dispatch at large batch)
+per_wg = {"tictactoe": 14, "connect4": int(os.environ.get("MZ_SPLIT_BOARDS", "2"))}.get(game, 4)    # boards per workgroup (board_conv.hip's dispatch at large batch)
 names = ["zero LDS", "input fill", "main loops (MFMA)", "epilogues", "barrier after a layer", "exports + rescale"]
 vals = [int(stamps[i]) for i in range(6)]
 total = sum(vals) or 1
-print(json.dumps({"game": game, "boards": boards, "switches": extra, "shares": {n: round(v / total, 4) for n, v in zip(names, vals)},
+print(json.dumps({"game": game, "boards": boards, "switches": extra, "env": {k: v for k, v in os.environ.items() if k.startswith("MZ_")}, "shares": {n: round(v / total, 4) for n, v in zip(names, vals)},
                   "cycles_per_workgroup_wave0": {n: round(v / 10 / max(1, -(-boards // per_wg))) for n, v in zip(names, vals)}}))
