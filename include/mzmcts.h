@@ -343,6 +343,13 @@ int mzmcts_moves_collect(mzmcts_engine *engine, int32_t *moves_done, int32_t *ac
  * moves_done[e] are undefined (its action reads -1 in the first such move). */
 int mzmcts_moves_ring(mzmcts_engine *engine, void **host_base, int64_t *move_stride, int64_t *offsets,
                       int32_t *capacity_moves);
+/* The same for what mzmcts_moves_inputs unpacks (device-input batches): one block per move with num_legal i32[E],
+ * to_play i32[E], legal i32[E][A] at offsets[0..2].
+ * Device-input batches alternate between TWO rings of each kind (mzmcts_moves_prepare_device switches): a lock-step
+ * move's blocks are downloaded as soon as the move has run (mzmcts_moves_end_lockstep, on a copy stream of the engine),
+ * so both calls return the ring of the batch prepared last, and views of a collected batch stay valid while the NEXT
+ * batch runs and is collected -- until the mzmcts_moves_prepare_device after that. */
+int mzmcts_moves_inputs_ring(mzmcts_engine *engine, void **host_base, int64_t *move_stride, int64_t *offsets);
 
 /* ---- residual-network epilogue (no engine: any device tensor of the current device) ---------
  * What follows every convolution of the reference's residual networks in eval() -- BatchNorm2d with its

@@ -120,6 +120,7 @@ PROTOTYPES = {
     "mzmcts_moves_finished": (ctypes.c_int, [c_void, c_void]),
     "mzmcts_moves_actions": (c_void, [c_void, ctypes.c_int32]),
     "mzmcts_moves_ring": (ctypes.c_int, [c_void, ctypes.POINTER(c_void), c_i64_p, c_i64_p, c_i32_p]),
+    "mzmcts_moves_inputs_ring": (ctypes.c_int, [c_void, ctypes.POINTER(c_void), c_i64_p, c_i64_p]),
     "mzmcts_moves_collect": (ctypes.c_int, [c_void, c_i32_p, c_i32_p, c_i32_p, c_f64_p, c_f32_p, c_i32_p, c_void]),
     "mzmcts_set_profiling": (ctypes.c_int, [c_void, ctypes.c_int32]),
     "mzmcts_set_select_queue": (ctypes.c_int, [c_void, ctypes.c_int32]),

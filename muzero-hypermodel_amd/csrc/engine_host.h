@@ -235,9 +235,20 @@ struct mzmcts_engine {
     mz::MinMax* h_min_max = nullptr;
     int32_t* h_error_flag = nullptr;
 
-    // host RNG mirrors; lag[e] = words the host stream is ahead of the device copy
+    // host RNG mirrors; lag[e] = words the host stream is ahead of the device copy.  behind[e] = words the device copy
+    // consumed that the mirror has not stepped over yet (device-input move batches draw everything on the device: their
+    // collect only counts); mirror(e) steps over them the first time anything asks for env e's stream again.
     std::vector<mz::HostStream> streams;
     std::vector<uint32_t> lag;
+    std::vector<uint64_t> behind;
+    mz::HostStream& mirror(int e) {
+        mz::HostStream& s = streams[static_cast<size_t>(e)];
+        if (behind[static_cast<size_t>(e)]) {
+            s.skip(behind[static_cast<size_t>(e)]);
+            behind[static_cast<size_t>(e)] = 0;
+        }
+        return s;
+    }
 
     // cache of the last readout (sample_actions / search_statistics)
     std::vector<int32_t> last_visits;       // [E][A] per slot
@@ -308,7 +319,15 @@ struct mzmcts_engine {
         size_t o_actions = 0, o_visits = 0, o_rvs = 0, o_pred = 0, o_depth = 0, o_ties = 0, o_sample = 0, o_dsum = 0;
         size_t in_bytes = 0, o_skip = 0, o_temp = 0, o_limit = 0, o_expect = 0;
         uint8_t* d_in = nullptr;
-        uint8_t *h_out = nullptr, *d_out = nullptr;  // [M] output blocks
+        uint8_t *h_out = nullptr, *d_out = nullptr;  // [M] output blocks (h_out = h_out_set[host_set])
+        // Two pinned download sets, alternating per device-input batch: a batch's blocks are downloaded move by move
+        // on `copy_stream` while the batch runs (mzmcts_moves_end_lockstep), and the views the host took of the batch
+        // before stay valid while it does.  `downloaded` = moves of the batch in flight whose downloads are queued.
+        uint8_t* h_out_set[2] = {nullptr, nullptr};
+        uint8_t* h_inputs_set[2] = {nullptr, nullptr};
+        int host_set = 0, downloaded = 0;
+        hipStream_t copy_stream = nullptr;
+        hipEvent_t move_done = nullptr;
         uint8_t* d_stall = nullptr;
         hipEvent_t done = nullptr;
         // batches whose inputs live on the device (mzmcts_moves_prepare_device): the legal sets / players to move the

@@ -169,6 +169,7 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
     if ((rc = pinned_alloc(eng, &eng->h_slab0, static_cast<size_t>(E) * p.line_stride))) return cleanup_on(rc);
 
     eng->streams.resize(E);
+    eng->behind.assign(E, 0);
     eng->lag.assign(E, 0u);
     eng->last_visits.assign(static_cast<size_t>(E) * A, 0);
     eng->last_root_value_sum.assign(E, 0.0);
@@ -195,6 +196,11 @@ void mzmcts_destroy(mzmcts_engine* eng) {
     }
     if (eng->readout_event) (void)hipEventDestroy(eng->readout_event);
     if (eng->batch.done) (void)hipEventDestroy(eng->batch.done);
+    if (eng->batch.move_done) (void)hipEventDestroy(eng->batch.move_done);
+    if (eng->batch.copy_stream) {
+        (void)hipStreamSynchronize(eng->batch.copy_stream);
+        (void)hipStreamDestroy(eng->batch.copy_stream);
+    }
     for (void* ptr : eng->device_allocs) (void)hipFree(ptr);
     for (void* ptr : eng->pinned_allocs) (void)hipHostFree(ptr);
     delete eng;
@@ -205,7 +211,10 @@ int mzmcts_seed(mzmcts_engine* eng, const uint32_t* seeds, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int E = eng->p.E;
     eng->for_each_env([&](int lo, int hi) {
-        for (int e = lo; e < hi; ++e) eng->streams[e].seed(seeds[e]);
+        for (int e = lo; e < hi; ++e) {
+            eng->streams[e].seed(seeds[e]);
+            eng->behind[e] = 0;
+        }
     });
     std::fill(eng->lag.begin(), eng->lag.end(), 0u);
     MZ_HIP(eng, hipMemcpyAsync(eng->d_seeds, seeds, sizeof(uint32_t) * E, hipMemcpyHostToDevice, stream));
@@ -219,6 +228,7 @@ int mzmcts_rng_set_state(mzmcts_engine* eng, int32_t env, const uint32_t* key, i
     if (!eng || !key || env < 0 || env >= eng->p.E || pos < 0 || pos > mz::kMtN)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_rng_set_state: bad argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    eng->behind[env] = 0;                              // (the state replaces whatever the mirror still owed)
     mz::HostStream& s = eng->streams[env];
     std::memcpy(s.key, key, sizeof(s.key));
     s.pos = pos;
@@ -237,7 +247,7 @@ int mzmcts_rng_get_state(mzmcts_engine* eng, int32_t env, uint32_t* key, int32_t
     if (!eng || !key || !pos || env < 0 || env >= eng->p.E)
         return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_rng_get_state: bad argument");
     (void)stream_;
-    const mz::HostStream& s = eng->streams[env];  // the host mirror is authoritative between calls
+    const mz::HostStream& s = eng->mirror(env);  // the host mirror is authoritative between calls
     std::memcpy(key, s.key, sizeof(s.key));
     *pos = s.pos;
     if (has_gauss) *has_gauss = s.has_gauss;
@@ -280,7 +290,7 @@ int mzmcts_begin_search(mzmcts_engine* eng, const int32_t* legal, const int32_t*
                 continue;
             }
             if (add_noise && !on_device) {
-                mz::HostStream& s = eng->streams[e];
+                mz::HostStream& s = eng->mirror(e);
                 const uint64_t before = s.words;
                 s.dirichlet(alpha, n, row);
                 eng->lag[e] += static_cast<uint32_t>(s.words - before);
@@ -546,7 +556,7 @@ int mzmcts_readout(mzmcts_engine* eng, const mzmcts_root_stats* out, void* strea
             if (is_active) {
                 // the tie-breaks ran on the device copy of the stream: bring the host mirror level (once)
                 // (and, when the device drew this search's exploration noise, the Dirichlet draw before them)
-                if (first) eng->streams[e].skip((eng->noise_on_device ? eng->h_noise_words[e] : 0u) + eng->h_tie_words[e]);
+                if (first) eng->mirror(e).skip((eng->noise_on_device ? eng->h_noise_words[e] : 0u) + eng->h_tie_words[e]);
                 local_depth += eng->h_depth_sum[e];
                 ++local_active;
             }
@@ -588,7 +598,7 @@ int mzmcts_sample_actions(mzmcts_engine* eng, const double* temperature, int32_t
                 if (slot_out) slot_out[e] = -1;
                 continue;
             }
-            mz::HostStream& s = eng->streams[e];
+            mz::HostStream& s = eng->mirror(e);
             const uint64_t before = s.words;
             const int slot = s.select_action(eng->last_visits.data() + static_cast<size_t>(e) * A, n, temperature[e]);
             eng->lag[e] += static_cast<uint32_t>(s.words - before);

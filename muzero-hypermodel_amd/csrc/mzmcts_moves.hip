@@ -22,7 +22,7 @@ extern "C" {
 // first).  Only the first regeneration of a set is backed up, so: if a backed-up block covers the target, use
 // it directly; otherwise start from the latest backup before the target and walk forward.
 static void restore_stream(mzmcts_engine* eng, int e, const MoveRecord& target, ChainSet* const* sets, int n_sets) {
-    mz::HostStream& s = eng->streams[e];
+    mz::HostStream& s = eng->mirror(e);
     const ChainSet* before = nullptr;
     const ChainSet* covering = nullptr;
     for (int i = 0; i < n_sets; ++i) {
@@ -73,9 +73,13 @@ static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
     int rc;  // (earlier, smaller buffers stay registered with the engine and are freed with it)
     if ((rc = dev_alloc(eng, &b.d_in, b.in_bytes))) return rc;
     if ((rc = dev_alloc(eng, &b.d_out, b.out_stride * M))) return rc;
-    if ((rc = pinned_alloc(eng, &b.h_out, b.out_stride * M))) return rc;
+    for (int q = 0; q < 2; ++q)
+        if ((rc = pinned_alloc(eng, &b.h_out_set[q], b.out_stride * M))) return rc;
+    b.h_out = b.h_out_set[b.host_set];
     if (!b.d_stall && (rc = dev_alloc(eng, &b.d_stall, E))) return rc;
     if (!b.done) MZ_HIP(eng, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    if (!b.move_done) MZ_HIP(eng, hipEventCreateWithFlags(&b.move_done, hipEventDisableTiming));
+    if (!b.copy_stream) MZ_HIP(eng, hipStreamCreateWithFlags(&b.copy_stream, hipStreamNonBlocking));
     for (ChainSet& c : b.set) {
         if ((rc = pinned_alloc(eng, &c.h_in, b.in_bytes))) return rc;
         c.legal.assign(E * A, 0);
@@ -96,7 +100,7 @@ static int ensure_batch_capacity(mzmcts_engine* eng, int n_moves) {
     // Run both transfers once at full size: the runtime sets up its large-copy path on first use (tens of
     // milliseconds), which would otherwise land in the first full-size batch.
     MZ_HIP(eng, hipMemcpy(b.d_in, b.set[0].h_in, b.in_bytes, hipMemcpyHostToDevice));
-    MZ_HIP(eng, hipMemcpy(b.h_out, b.d_out, b.out_stride * M, hipMemcpyDeviceToHost));
+    for (int q = 0; q < 2; ++q) MZ_HIP(eng, hipMemcpy(b.h_out_set[q], b.d_out, b.out_stride * M, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -152,7 +156,7 @@ static bool draw_env_rows(mzmcts_engine* eng, ChainSet& c, int e, bool tail, con
     h_expect[e] = tie_words;
     c.env_twisted[e] = 0;
     c.deferred[e] = 0;
-    mz::HostStream& s = eng->streams[e];
+    mz::HostStream& s = eng->mirror(e);
     uint32_t lag0 = eng->lag[e];
     if (tail && n > 0) {
         const int under_n = under->nlegal[e];
@@ -263,7 +267,9 @@ static int ensure_inputs_capacity(mzmcts_engine* eng, int n_moves) {
     b.in2_stride = align(b.o2_legal + sizeof(int32_t) * E * A);
     int rc;
     if ((rc = dev_alloc(eng, &b.d_inputs, b.in2_stride * static_cast<size_t>(n_moves)))) return rc;
-    if ((rc = pinned_alloc(eng, &b.h_inputs, b.in2_stride * static_cast<size_t>(n_moves)))) return rc;
+    for (int q = 0; q < 2; ++q)
+        if ((rc = pinned_alloc(eng, &b.h_inputs_set[q], b.in2_stride * static_cast<size_t>(n_moves)))) return rc;
+    b.h_inputs = b.h_inputs_set[b.host_set];
     b.inputs_capacity = n_moves;
     return 0;
 }
@@ -291,6 +297,10 @@ int mzmcts_moves_prepare_device(mzmcts_engine* eng, int32_t n_moves, const int32
     if ((rc = ensure_batch_capacity(eng, n_moves))) return rc;
     if ((rc = ensure_inputs_capacity(eng, n_moves))) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    b.host_set ^= 1;                                 // (the batch before keeps its downloads: the host may still be filing them)
+    b.h_out = b.h_out_set[b.host_set];
+    b.h_inputs = b.h_inputs_set[b.host_set];
+    b.downloaded = 0;
     ChainSet& c = b.set[b.cur];
     c.n_moves = n_moves;
     c.add_noise = add_noise != 0;
@@ -384,7 +394,7 @@ int mzmcts_moves_discard_next(mzmcts_engine* eng) {
             if (c.deferred[e]) continue;  // nothing was drawn for this env
             restore_stream(eng, e, c.start[e], sets, 1);
             // what the finished batch's last move consumed was confirmed by its collect(): step over it again
-            eng->streams[e].skip(static_cast<uint64_t>(c.tail_ties[e]) + c.tail_sample[e]);
+            eng->mirror(e).skip(static_cast<uint64_t>(c.tail_ties[e]) + c.tail_sample[e]);
             eng->lag[e] = (c.tail_ties[e] | c.tail_sample[e]) ? 0u : c.start_lag[e];
         }
     });
@@ -563,6 +573,15 @@ int mzmcts_moves_end_lockstep(mzmcts_engine* eng, void* stream_) {
     }
     hipError_t err = mz::launch_lockstep_move_finish(eng->p, ctl, stream);
     if (err != hipSuccess) return hip_fail(eng, err, "lockstep_move_finish_kernel");
+    // the move's blocks go to the host now, under the batch's remaining searches (collect then finds them there)
+    if (b.downloaded == m) {
+        MZ_HIP(eng, hipEventRecord(b.move_done, stream));
+        MZ_HIP(eng, hipStreamWaitEvent(b.copy_stream, b.move_done, 0));
+        MZ_HIP(eng, hipMemcpyAsync(b.h_out + b.out_stride * static_cast<size_t>(m), out, b.out_stride, hipMemcpyDeviceToHost, b.copy_stream));
+        MZ_HIP(eng, hipMemcpyAsync(b.h_inputs + b.in2_stride * static_cast<size_t>(m), b.d_inputs + b.in2_stride * static_cast<size_t>(m),
+                                   b.in2_stride, hipMemcpyDeviceToHost, b.copy_stream));
+        b.downloaded = m + 1;
+    }
     b.lockstep_open = false;
     b.enqueued = m + 1;
     eng->search_begun = false;
@@ -592,6 +611,18 @@ int mzmcts_moves_ring(mzmcts_engine* eng, void** host_base, int64_t* move_stride
     return MZMCTS_OK;
 }
 
+int mzmcts_moves_inputs_ring(mzmcts_engine* eng, void** host_base, int64_t* move_stride, int64_t* offsets) {
+    if (!eng || !host_base || !move_stride || !offsets) return MZMCTS_ERR_INVALID;
+    mzmcts_engine::MoveBatch& b = eng->batch;
+    if (!b.h_inputs) return fail(eng, MZMCTS_ERR_INVALID, "mzmcts_moves_inputs_ring: no device-input batch has been prepared yet");
+    *host_base = b.h_inputs;
+    *move_stride = static_cast<int64_t>(b.in2_stride);
+    offsets[0] = static_cast<int64_t>(b.o2_nlegal);
+    offsets[1] = static_cast<int64_t>(b.o2_to_play);
+    offsets[2] = static_cast<int64_t>(b.o2_legal);
+    return MZMCTS_OK;
+}
+
 int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actions, int32_t* visits, double* root_value_sum,
                          float* root_predicted, int32_t* max_depth, void* stream_) {
     if (!eng) return MZMCTS_ERR_INVALID;
@@ -605,9 +636,16 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
     MZ_HIP(eng, hipEventRecord(b.done, stream));
     MZ_HIP(eng, hipEventSynchronize(b.done));
     const double t_kernels = trace ? now() : 0.0;
-    if (M > 0) MZ_HIP(eng, hipMemcpyAsync(b.h_out, b.d_out, b.out_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
-    if (M > 0 && b.device_inputs)
-        MZ_HIP(eng, hipMemcpyAsync(b.h_inputs, b.d_inputs, b.in2_stride * static_cast<size_t>(M), hipMemcpyDeviceToHost, stream));
+    const int have = b.device_inputs ? std::min(b.downloaded, M) : 0;      // moves downloaded while the batch ran
+    if (M > have) {
+        MZ_HIP(eng, hipMemcpyAsync(b.h_out + b.out_stride * static_cast<size_t>(have), b.d_out + b.out_stride * static_cast<size_t>(have),
+                                   b.out_stride * static_cast<size_t>(M - have), hipMemcpyDeviceToHost, stream));
+        if (b.device_inputs)
+            MZ_HIP(eng, hipMemcpyAsync(b.h_inputs + b.in2_stride * static_cast<size_t>(have), b.d_inputs + b.in2_stride * static_cast<size_t>(have),
+                                       b.in2_stride * static_cast<size_t>(M - have), hipMemcpyDeviceToHost, stream));
+    }
+    if (have > 0) MZ_HIP(eng, hipStreamSynchronize(b.copy_stream));
+    b.downloaded = 0;
     MZ_HIP(eng, hipMemcpyAsync(eng->h_error_flag, eng->p.error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     MZ_HIP(eng, hipEventRecord(b.done, stream));
     MZ_HIP(eng, hipEventSynchronize(b.done));
@@ -653,7 +691,7 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
                 }
                 // (an env that searched nothing kept the pending words of its mirror: they were not stepped over)
                 if (k == 0) eng->lag[e] += reinterpret_cast<const uint32_t*>(c.h_in + b.o_skip)[e];
-                eng->streams[e].skip(words);
+                eng->behind[e] += words;             // (stepped over when the mirror is next asked for: mirror())
                 local += k;
             }
             played_total.fetch_add(local, std::memory_order_relaxed);
@@ -694,7 +732,7 @@ int mzmcts_moves_collect(mzmcts_engine* eng, int32_t* moves_done, int32_t* actio
             local += k;
             // The mirror ran ahead over this batch (and over the next one, if it is pre-drawn): put it where the
             // device copy really is, unless everything went as the draws assumed.
-            mz::HostStream& s = eng->streams[e];
+            mz::HostStream& s = eng->mirror(e);
             bool redraw_next = next.drawn && next.deferred[e];
             if (active) {
                 if (k == 0) {  // nothing was searched (batch collected before its first move ran): undo every draw

@@ -182,8 +182,24 @@ struct HostStream {
         ++words;
         return mt_next(key, &pos);
     }
+    // n draws whose values nobody looks at: what remains of the current block of 624 words is stepped over, further
+    // blocks are regenerated and stepped over (the state n calls of u32() leave behind, without tempering n words)
     void skip(uint64_t n) {
-        for (uint64_t i = 0; i < n; ++i) u32();
+        while (n > 0) {
+            if (pos >= kMtN) {
+                if (twist_backup && !twisted) {
+                    std::memcpy(twist_backup, key, sizeof(key));
+                    twisted = true;
+                    twist_words = words;
+                }
+                mt_regenerate(key);
+                pos = 0;
+            }
+            const uint64_t step = n < static_cast<uint64_t>(kMtN - pos) ? n : static_cast<uint64_t>(kMtN - pos);
+            pos += static_cast<int32_t>(step);
+            words += step;
+            n -= step;
+        }
     }
     // legacy_double: 53 random bits from two words
     double uniform() {

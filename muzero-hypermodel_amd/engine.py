@@ -560,9 +560,18 @@ class BatchedMCTS:
                                                           to_play_dev.data_ptr(), 1 if add_exploration_noise else 0,
                                                           ptr(temps, c_f64_p), self._stream()))
 
-    def moves_inputs(self, n_moves):
+    def moves_inputs(self, n_moves, copy=True):
         """What each move of the collected device-input batch was searched with: dict(num_legal [M, E], legal [M, E, A]
-        (child slot -> action), to_play [M, E])."""
+        (child slot -> action), to_play [M, E]).  copy=False: views of the library's pinned ring of this batch (valid
+        until the batch after the next one is prepared: include/mzmcts.h mzmcts_moves_inputs_ring)."""
+        if not copy:
+            base, stride = ctypes.c_void_p(), ctypes.c_int64()
+            offsets = (ctypes.c_int64 * 3)()
+            self._check(self._lib.mzmcts_moves_inputs_ring(self._h, ctypes.byref(base), ctypes.byref(stride), offsets))
+            raw = self._pinned_bytes(base.value, stride.value * int(n_moves))
+            view = lambda off, inner: _ring_view(raw, off, stride.value, np.int32, int(n_moves), inner)
+            return dict(num_legal=view(offsets[0], (self.E,)), to_play=view(offsets[1], (self.E,)),
+                        legal=view(offsets[2], (self.E, self.A)))
         out = dict(num_legal=np.zeros((n_moves, self.E), np.int32), legal=np.zeros((n_moves, self.E, self.A), np.int32),
                    to_play=np.zeros((n_moves, self.E), np.int32))
         self._check(self._lib.mzmcts_moves_inputs(self._h, ptr(out["num_legal"], c_i32_p), ptr(out["legal"], c_i32_p),
@@ -618,18 +627,23 @@ class BatchedMCTS:
             raise RuntimeError("no such move in the prepared batch")
         return _device_view(addr, self.E, torch.int32, self.device)
 
+    def _pinned_bytes(self, address, nbytes):
+        """numpy byte view of `nbytes` of the library's pinned memory at `address` (built once per (address, size))."""
+        views = self.__dict__.setdefault("_pinned_views", {})
+        key = (address, nbytes)
+        if key not in views:
+            if len(views) > 16:                    # (rings are re-allocated only when a larger batch is prepared)
+                views.clear()
+            views[key] = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(address), dtype=np.uint8)
+        return views[key]
+
     def _moves_ring(self):
-        """numpy byte view of the library's pinned download ring (built once per ring allocation)."""
+        """numpy byte view of the library's pinned download ring of the batch prepared last."""
         base, stride = ctypes.c_void_p(), ctypes.c_int64()
         offsets = (ctypes.c_int64 * 8)()
         self._check(self._lib.mzmcts_moves_ring(self._h, ctypes.byref(base), ctypes.byref(stride), offsets,
                                                 ctypes.byref(self._ring_moves)))
-        key = (base.value, stride.value, self._ring_moves.value)
-        if getattr(self, "_ring_key", None) != key:
-            nbytes = stride.value * self._ring_moves.value
-            self._ring_raw = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(base.value), dtype=np.uint8)
-            self._ring_key = key
-        return self._ring_raw, stride.value, list(offsets)
+        return self._pinned_bytes(base.value, stride.value * self._ring_moves.value), stride.value, list(offsets)
 
     def moves_collect(self, copy=True):
         """Wait for the queued searches.  Returns dict(moves_done [E], actions [M,E], visits [M,E,A],
@@ -650,13 +664,7 @@ class BatchedMCTS:
             self._check(self._lib.mzmcts_moves_collect(self._h, ptr(out["moves_done"], c_i32_p), None, None, None, None,
                                                        None, self._stream()))
             raw, stride, offsets = self._moves_ring()
-
-            def view(offset, dtype, inner):
-                itemsize = np.dtype(dtype).itemsize
-                return np.lib.stride_tricks.as_strided(
-                    raw[offset:].view(dtype), shape=(M,) + inner,
-                    strides=(stride,) + tuple(itemsize * int(np.prod(inner[i + 1:])) for i in range(len(inner))),
-                    writeable=False)
+            view = lambda offset, dtype, inner: _ring_view(raw, offset, stride, dtype, M, inner)
             out.update(actions=view(offsets[0], np.int32, (self.E,)), visits=view(offsets[1], np.int32, (self.E, self.A)),
                        root_value_sum=view(offsets[2], np.float64, (self.E,)),
                        root_predicted=view(offsets[3], np.float32, (self.E,)), max_depth=view(offsets[4], np.int32, (self.E,)))
@@ -768,6 +776,14 @@ class BatchedMCTS:
         select = mean_depth * (8 + 24 * A) + 2 * 4 * H
         backup = (mean_depth + 1) * (28 + two) + 32 + 24 * A + 13 + 4 * (A + 2 * F)
         return dict(select=select, expand_backup=backup, total=select + backup)
+
+
+def _ring_view(raw, offset, stride, dtype, n_moves, inner):
+    """[n_moves] + inner view of one field of a pinned ring of per-move blocks `stride` bytes apart (read-only)."""
+    itemsize = np.dtype(dtype).itemsize
+    return np.lib.stride_tricks.as_strided(
+        raw[offset:].view(dtype), shape=(n_moves,) + tuple(inner),
+        strides=(stride,) + tuple(itemsize * int(np.prod(inner[i + 1:])) for i in range(len(inner))), writeable=False)
 
 
 def _device_view(address, numel, dtype, device):

@@ -803,8 +803,14 @@ class HistoryFiler:
         Returns PackedGames of the games that ended, or None."""
         ct = self._ct
         M = int(out["actions"].shape[0])
+        def per_move_rows(a):
+            # a per-move array whose rows are contiguous goes as it is (ring views: rows a block stride apart)
+            a = numpy.asarray(a)
+            inner = numpy.empty(a.shape[1:], dtype=numpy.int32).strides
+            return a if a.dtype == numpy.int32 and a.ndim >= 2 and a.strides[1:] == inner else numpy.ascontiguousarray(a, dtype=numpy.int32)
         keep = [numpy.ascontiguousarray(out["moves_done"], dtype=numpy.int32),
-                numpy.ascontiguousarray(legal, dtype=numpy.int32), numpy.ascontiguousarray(num_legal, dtype=numpy.int32),
+                per_move_rows(legal) if numpy.ndim(legal) == 3 else numpy.ascontiguousarray(legal, dtype=numpy.int32),
+                per_move_rows(num_legal) if numpy.ndim(legal) == 3 else numpy.ascontiguousarray(num_legal, dtype=numpy.int32),
                 numpy.ascontiguousarray(rewards, dtype=numpy.float32), numpy.ascontiguousarray(done, dtype=numpy.uint8),
                 numpy.ascontiguousarray(obs_after, dtype=numpy.float32), numpy.ascontiguousarray(obs_next, dtype=numpy.float32)]
         mv = self._native.MzHistMoves()
@@ -898,6 +904,13 @@ class DeviceSelfPlay(ManyEnvLoop):
         return dict(obs=obs.cpu().numpy(), legal=legal.cpu().numpy(), num_legal=num_legal.cpu().numpy(),
                     to_play=to_play.cpu().numpy(), obs_dev=obs)
 
+    def _current(self):
+        """The envs' current positions on the host (what step() searches).  A device-input move batch leaves them on the
+        device only: they are fetched when a step() next asks, not once per batch."""
+        if self._cur.get("on_device_only"):
+            self._cur = self._observe_host()
+        return self._cur
+
     def set_weights(self, weights):
         self.model.set_weights(weights)
 
@@ -918,7 +931,7 @@ class DeviceSelfPlay(ManyEnvLoop):
         self._no_opponent()
         self.flush(on_game, on_games)      # first: the unfiled batch holds views of the download ring
         self._drop_batch()
-        cur = self._cur
+        cur = self._current()
         if self.engine._fc_model is not None:
             self.engine.search_fused_begin(cur["obs_dev"].reshape(self.E, -1), cur["legal"], cur["to_play"], True,
                                            num_legal=cur["num_legal"])
@@ -1013,7 +1026,7 @@ class DeviceSelfPlay(ManyEnvLoop):
             temperature_threshold = cfg.temperature_threshold
         if not getattr(envs, "constant_legal_actions", False) or eng._fc_model is None or temperature_threshold:
             return self._play_moves_device_inputs(n_moves, temperature, on_game, on_games, temperature_threshold)
-        cur = self._cur
+        cur = self._current()
         params = (int(n_moves), float(temperature))
         if getattr(self, "_batch_ready", None) != params:
             self.flush(on_game, on_games)                    # (the unfiled batch holds views of the download ring)
@@ -1098,8 +1111,10 @@ class DeviceSelfPlay(ManyEnvLoop):
         n_moves, ring = b["n_moves"], b["ring"]
         self._dev_batch = None
         self.flush(on_game, on_games)                        # the previous batch's games, while this one runs
-        out = eng.moves_collect()
-        inputs = eng.moves_inputs(n_moves)
+        # (views of the engine's pinned rings, filled move by move while the batch ran: nothing is unpacked here; they
+        # stay valid until the batch after the next one is prepared, and flush() files them before that)
+        out = eng.moves_collect(copy=False)
+        inputs = eng.moves_inputs(n_moves, copy=False)
         pinned = b["pinned"]
         last_to_play = envs.to_play.cpu().numpy()
         self._copy_stream.synchronize()                  # (the last move's downloads)
@@ -1109,22 +1124,27 @@ class DeviceSelfPlay(ManyEnvLoop):
         to_play_after = (1 - to_play) if two_players else numpy.zeros_like(to_play)
         to_play_next = numpy.concatenate([to_play[1:], last_to_play[None]], axis=0)
         self._unfiled = (out, host, inputs["legal"], inputs["num_legal"], n_moves, to_play_after, to_play_next)
-        nxt = self._observe_host()                       # (the envs' current state: what the next step / batch searches)
-        self._cur = nxt
+        # the envs' current positions stay on the device: the next batch starts from the last move's observation (the
+        # kernels' output, where it lies); a step() fetches what it needs first (_current)
+        self._cur = dict(obs_dev=b["obs_in"], on_device_only=True)
         self.moves_played += int(out["moves_done"].sum())
         return out["moves_done"].copy()
+
+    def _batchable(self, temperature, temperature_threshold, moves_per_pass, device_inputs=None):
+        """Can a pass of `moves_per_pass` moves run as one move batch on the device (play_moves)?"""
+        if device_inputs is None:
+            device_inputs = (not getattr(self.envs, "constant_legal_actions", False) or self.engine._fc_model is None
+                             or bool(temperature_threshold))
+        return (moves_per_pass is not None and self.config.max_moves >= self.envs.max_episode_steps
+                and getattr(self, "_opponent", ("self", 0))[0] == "self"
+                and (temperature == 0 or _native.exact_inverse_temperature(temperature))
+                # (a device-input batch draws its exploration noise on the GPU: the legacy gamma sampler for shapes <= 1)
+                and (not device_inputs or 0.0 < float(self.config.root_dirichlet_alpha) <= 1.0))
 
     def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
         """ManyEnvLoop's pass: whole move batches on the device when the game, the network and the temperature allow
         it (play_moves), else one move at a time (step)."""
-        device_inputs = (not getattr(self.envs, "constant_legal_actions", False) or self.engine._fc_model is None
-                         or bool(temperature_threshold))
-        batchable = (moves_per_pass is not None and self.config.max_moves >= self.envs.max_episode_steps
-                     and getattr(self, "_opponent", ("self", 0))[0] == "self"
-                     and (temperature == 0 or _native.exact_inverse_temperature(temperature))
-                     # (a device-input batch draws its exploration noise on the GPU: the legacy gamma sampler for shapes <= 1)
-                     and (not device_inputs or 0.0 < float(self.config.root_dirichlet_alpha) <= 1.0))
-        if not batchable:
+        if not self._batchable(temperature, temperature_threshold, moves_per_pass):
             return ManyEnvLoop._play_pass(self, temperature, temperature_threshold, moves_per_pass)
         finished = []
         self.play_moves(moves_per_pass, temperature, on_game=lambda e, gh: finished.append((e, gh)),
@@ -1210,6 +1230,7 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
         self.device, self.model = self.actors[0].device, self.actors[0].model   # (what ManyEnvLoop's weight pull addresses)
 
     def _pull_weights(self, shared_storage, version):
+        self._no_batch_queued("weight pull")
         ManyEnvLoop._pull_weights(self, shared_storage, version)     # group 0's model (all ranks: one flat broadcast)
         # the replicas take the parameters AND rebuild what they cache from them (folded batch norms, packed tower
         # weights): a replayed hipGraph reads those buffers without coming back to Python
@@ -1229,6 +1250,7 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
         return sum(a.games_finished for a in self.actors)
 
     def set_weights(self, weights):
+        self._no_batch_queued("set_weights")
         for a in self.actors:
             a.set_weights(weights)
 
@@ -1250,6 +1272,7 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
         """One move in every env of every group (each group's search was queued during the previous call).
         prefetch=False leaves no search queued behind (the next call then starts them): what a caller wants before it
         changes the weights, so that no move is searched with the weights of the move before."""
+        self._no_batch_queued("step")
         for g, actor in enumerate(self.actors):
             actor._opponent = getattr(self, "_opponent", ("self", 0))
             if not self._started[g]:
@@ -1265,15 +1288,24 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
                     actor.step_begin(one, many)      # the next move's search runs while the other groups are served
                     self._started[g] = True
 
-    def play_moves(self, n_moves, temperature, on_game=None, on_games=None, temperature_threshold=None):
+    def play_moves(self, n_moves, temperature, on_game=None, on_games=None, temperature_threshold=None, prefetch=False):
         """`n_moves` moves of every env of every group with no host round trip (DeviceSelfPlay.play_moves in its
         device-input form): each group's batch is queued on the group's own stream, move by move in turn, so the
         kernels of the groups fill each other's gaps (a tower workgroup's fill / epilogue / export phases leave the matrix
-        pipe idle) and one group's collect / filing runs under the other's kernels.  Returns moves played per env."""
+        pipe idle).  Returns moves played per env.
+
+        prefetch=True queues each group's NEXT batch (same parameters) as soon as its current one is collected, before
+        anything is filed: collecting, filing and the callbacks of one group then run under the other group's kernels
+        and the GPU never drains between calls -- the batch form of step()'s prefetch, with the same contract: the batch a
+        call returns was queued by the call before (with that call's parameters and the weights of that time), and
+        the last call before the weights change passes prefetch=False."""
         cfg = self.config
         if temperature_threshold is None:
             temperature_threshold = cfg.temperature_threshold
-        for g, actor in enumerate(self.actors):
+        queued = self.__dict__.setdefault("_batch_queued", [False] * self.groups)
+        fresh = [g for g in range(self.groups) if not queued[g]]
+        for g in fresh:
+            actor = self.actors[g]
             if self._started[g]:                             # (a search queued by step(): finish that move first)
                 raise RuntimeError("play_moves: a step() is half done; call step(..., prefetch=False) before batches")
             if cfg.max_moves < actor.envs.max_episode_steps:
@@ -1282,19 +1314,41 @@ class PipelinedDeviceSelfPlay(ManyEnvLoop):
             with torch.cuda.stream(self.streams[g]):
                 actor._device_batch_begin(n_moves, temperature, one, many, temperature_threshold)
         for m in range(n_moves):
-            for g, actor in enumerate(self.actors):
+            for g in fresh:
                 with torch.cuda.stream(self.streams[g]):
-                    actor._device_batch_move(m)
+                    self.actors[g]._device_batch_move(m)
+        for g in fresh:
+            queued[g] = True
         played = []
         for g, actor in enumerate(self.actors):
             one, many = self._callbacks(g, on_game, on_games)
             with torch.cuda.stream(self.streams[g]):
                 played.append(actor._device_batch_end(one, many))
+                queued[g] = False
+                if prefetch:
+                    actor._device_batch_begin(n_moves, temperature, one, many, temperature_threshold)
+                    for m in range(n_moves):
+                        actor._device_batch_move(m)
+                    queued[g] = True
+                    actor.flush(one, many)                   # the collected batch's games, while the GPU runs the next
         return numpy.concatenate(played)
 
+    def _no_batch_queued(self, what):
+        if any(self.__dict__.get("_batch_queued", ())):
+            raise RuntimeError(f"{what}: a move batch is queued ahead; call play_moves(..., prefetch=False) first")
+
     def _play_pass(self, temperature, temperature_threshold, moves_per_pass):
-        """ManyEnvLoop's pass; the last move of a pass queues nothing behind it (a weight pull follows)."""
+        """ManyEnvLoop's pass: the groups' move batches on their streams when the pass can run as batches (always in their
+        device-input form; nothing stays queued behind the pass: a weight pull follows), else move by move with the
+        groups' halves alternating -- the last move of a pass queues nothing behind it either."""
         finished = []
+        for actor in self.actors:
+            actor._opponent = getattr(self, "_opponent", ("self", 0))
+        if self.actors[0]._batchable(temperature, temperature_threshold, moves_per_pass, device_inputs=True):
+            collect = lambda e, gh: finished.append((e, gh))
+            self.play_moves(moves_per_pass, temperature, on_game=collect, temperature_threshold=temperature_threshold or 0)
+            self.flush(on_game=collect)
+            return finished
         moves = 0
         while True:
             last = moves_per_pass is None or moves + 1 >= moves_per_pass

@@ -429,3 +429,42 @@ def test_pipelined_groups_play_lockstep_move_batches_like_one_actor(dev, pkg):
     got, _ = _games_by_env(sp, lambda: sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2,
                                                                   use_graph=True), by_batches)
     _assert_same_games(want, got, E, at_least=E)
+
+
+def test_pipelined_move_batches_queued_ahead_play_the_same_games(dev, pkg):
+    """play_moves(prefetch=True): each group's next batch is queued the moment its current one is collected (filing and
+    callbacks run under the other group's kernels; the call returns the batch queued by the call before).  Same games as
+    one actor stepping move by move; step(), set_weights and a weight pull refuse while a batch is queued ahead."""
+    sp = importlib.import_module("muzero-hypermodel_amd.self_play")
+    models_mod = importlib.import_module("muzero-hypermodel_amd.models")
+    config = games("tictactoe").MuZeroConfig()
+    config.temperature_threshold = 5
+    _, weights = synthetic_model(models_mod, config, "cpu")
+    E, n, calls = 64, 6, 4
+
+    def by_step(actor, on_games):
+        for _ in range(n * calls):
+            actor.step(1.0, config.temperature_threshold, on_games=on_games)
+
+    def by_batches(actor, on_games):
+        played = np.zeros(E, np.int64)
+        for i in range(calls):
+            played += actor.play_moves(n, 1.0, on_games=on_games, prefetch=i + 1 < calls)
+            if i + 1 < calls:
+                with pytest.raises(RuntimeError, match="queued ahead"):
+                    actor.step(1.0, None, on_games=on_games)
+                with pytest.raises(RuntimeError, match="queued ahead"):
+                    actor.set_weights(weights)
+        actor.flush(on_games=on_games)
+        assert (played == n * calls).all()
+        actor.step(1.0, config.temperature_threshold, on_games=on_games, prefetch=False)     # drained: stepping works again
+
+    def by_step_plus_one(actor, on_games):
+        by_step(actor, on_games)
+        actor.step(1.0, config.temperature_threshold, on_games=on_games)
+
+    want, _ = _games_by_env(sp, lambda: sp.DeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, use_graph=False),
+                            by_step_plus_one)
+    got, _ = _games_by_env(sp, lambda: sp.PipelinedDeviceSelfPlay({"weights": weights}, "tictactoe", config, 0, E, groups=2,
+                                                                  use_graph=True), by_batches)
+    _assert_same_games(want, got, E, at_least=E)

@@ -30,6 +30,8 @@ def main():
                          "games and the benchmark's tree depths; random: seed-0 initialisation, games of ~15 moves")
     ap.add_argument("--fc", type=int, default=0, help="N > 0: play the game with a fully-connected network (the reference's "
                     "network = 'fullyconnected'), encoding and layers of N units -- board games through the fused whole-move search")
+    ap.add_argument("--no-prefetch", action="store_true", help="device-pipelined-batch: every play_moves call drains the GPU "
+                    "(what a loop does that pulls weights between calls)")
     args = ap.parse_args()
     mod = importlib.import_module(f"muzero-hypermodel_amd.games.{args.game}")
     config = mod.MuZeroConfig()
@@ -71,8 +73,11 @@ def main():
             done[0] = 0
             t0 = time.perf_counter()
             moves = 0
-            for _ in range(max(1, args.moves // args.batch)):
-                moves += int(actor.play_moves(args.batch, 1.0, **cb).sum())
+            calls = max(1, args.moves // args.batch)
+            for i in range(calls):
+                # (two groups: each group's next batch is queued before its last one is filed; the last call drains)
+                ahead = dict(prefetch=i + 1 < calls and not args.no_prefetch) if kind == "device-pipelined-batch" else {}
+                moves += int(actor.play_moves(args.batch, 1.0, **cb, **ahead).sum())
             actor.flush(**cb)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -89,7 +94,9 @@ def main():
             moves = args.moves * args.envs
         print(json.dumps({"actor": kind, "game": args.game, "envs": args.envs, "moves_per_s": moves / dt,
                           "simulations_per_s": moves * config.num_simulations / dt, "ms_per_move_step": 1e3 * dt * args.envs / moves,
-                          "games_finished": done[0], "weights": args.weights}), flush=True)
+                          "games_finished": done[0], "weights": args.weights,
+                          **({"moves_per_call": args.batch, "prefetch": not args.no_prefetch} if kind == "device-pipelined-batch" else {}),
+                          **({"moves_per_call": args.batch} if kind == "device-batch" else {})}), flush=True)
         actor.close()
 
 
