@@ -333,9 +333,8 @@ static __device__ unsigned long long g_tower_stamps[16];
 #endif
 
 template <int NT, int H, int W, int SB>
-__global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const float* __restrict__ x, int batch, int cin0,
-                                                                       uint32_t cin0_magic, int cp0, int cp1,
-                                                                       TowerArgs args, TowerGather gather) {
+__device__ __forceinline__ void board_tower_block(const float* __restrict__ x, int batch, int cin0, uint32_t cin0_magic, int cp0,
+                                                  int cp1, const TowerArgs& args, const TowerGather& gather, int block_index) {
     constexpr int P = H * W;
     constexpr int PW = W + 1;
     constexpr int PP = (H + 2) * PW + 1;
@@ -350,13 +349,8 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b0 = blockIdx.x * SB;
+    const int b0 = block_index * SB;
     const int n_samples = min(SB, batch - b0);
-    if (args.gate) {                                       // (uniform over the workgroup: before any barrier)
-        int flagged = 0;
-        for (int e = b0 / args.gate_samples; e <= (b0 + n_samples - 1) / args.gate_samples; ++e) flagged |= args.gate[e];
-        if (!flagged) return;
-    }
     const int buf1_at = SB * PP * cp0;                  // (offsets into lds, so that every access stays an LDS access)
     MZ_TSTAMP_DECL
 
@@ -596,6 +590,29 @@ __global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const floa
         }
     }
     MZ_TSTAMP_FLUSH;
+}
+
+// One workgroup per block of SB samples -- or, as the re-run behind a split-precision launch (args.gate), a grid of about
+// one workgroup per CU whose workgroups walk over the blocks and run the flagged ones: the usual case, nothing flagged,
+// then costs a few microseconds instead of the dispatch of batch / SB workgroups of 150 KB of LDS each (33 us per
+// launch at 8192 Connect4 boards, profiles/r03_bench_connect4_kernel_stats.csv before this).
+template <int NT, int H, int W, int SB>
+__global__ __launch_bounds__(64 * kConvWaves) void board_tower_kernel(const float* __restrict__ x, int batch, int cin0,
+                                                                       uint32_t cin0_magic, int cp0, int cp1,
+                                                                       TowerArgs args, TowerGather gather) {
+    if (!args.gate) {
+        board_tower_block<NT, H, W, SB>(x, batch, cin0, cin0_magic, cp0, cp1, args, gather, blockIdx.x);
+        return;
+    }
+    const int n_blocks = (batch + SB - 1) / SB;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int b0 = blk * SB, last = min(batch, b0 + SB) - 1;
+        int flagged = 0;                                   // (uniform over the workgroup)
+        for (int e = b0 / args.gate_samples; e <= last / args.gate_samples; ++e) flagged |= args.gate[e];
+        if (!flagged) continue;
+        board_tower_block<NT, H, W, SB>(x, batch, cin0, cin0_magic, cp0, cp1, args, gather, blk);
+        __syncthreads();                                   // (the next block zeroes the buffers this one still reads)
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1377,7 +1394,8 @@ static int launch_board_tower(const float* x, int batch, int cin0, const TowerAr
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                static_cast<int>(lds)) != hipSuccess)
         return MZMCTS_ERR_HIP;
-    const dim3 grid(static_cast<unsigned>((batch + SB - 1) / SB)), block(64 * kConvWaves);
+    const int blocks = (batch + SB - 1) / SB;
+    const dim3 grid(static_cast<unsigned>(args.gate ? std::min(blocks, 256) : blocks)), block(64 * kConvWaves);
     kernel<<<grid, block, lds, stream>>>(x, batch, cin0, 0xFFFFFFFFu / static_cast<uint32_t>(cin0) + 1u, cp0, cp1, args, gather);
     return hipGetLastError() == hipSuccess ? MZMCTS_OK : MZMCTS_ERR_HIP;
 }
