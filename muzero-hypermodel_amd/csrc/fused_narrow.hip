@@ -22,11 +22,13 @@ namespace mz {
 
 constexpr int kNarrowMaxThreads = 256;
 
-// lanes of the row that can hold a child (the kernel's SPAN template argument): 2, 4, 8 or 16
-static inline int narrow_vterm_shift(int A) {
-    int s = 1;
-    while ((1 << s) < A) ++s;
-    return s;
+// lanes of the row that can hold a child (the kernel's SPAN template argument): 2 (exactly two actions and block
+// indices that fit a byte: the windowed descent), 4, 8 or 16
+static inline int narrow_span(int A, int S) {
+    if (A == 2 && S <= 254) return 2;
+    int span = 4;
+    while (span < A) span <<= 1;
+    return span;
 }
 
 // Does this (engine, network) pair qualify for the narrow path?
@@ -45,16 +47,25 @@ bool narrow_supported(const TreeParams& p, const FcNet& net) {
 // SIMD); second pass: anything that fits a workgroup's 160 KB.  Returns false when nothing does.
 bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit, NarrowLayout* out) {
     auto align16 = [](size_t v) { return (v + 15) / 16 * 16; };
+    auto align64 = [](size_t v) { return (v + 63) / 64 * 64; };
     int rows = 4;
     if (const char* env = std::getenv("MZMCTS_NARROW_ROWS")) rows = std::max(1, std::min(4, std::atoi(env)));
+    int max_mode = 2;
+    if (const char* env = std::getenv("MZMCTS_NARROW_PBC2")) max_mode = std::max(0, std::min(2, std::atoi(env)));
+    const size_t span = static_cast<size_t>(narrow_span(p.A, p.S));
     for (int pass = 0; pass < 2; ++pass)
-    for (int with_pbc2 = 1; with_pbc2 >= 0; --with_pbc2) {
+    for (int mode = max_mode; mode >= 0; --mode) {
+        if (mode == 2 && p.S > 63) continue;   // rows of 64 entries: n <= N <= S
         for (int waves = 4; waves >= 1; waves >>= 1) {
             NarrowLayout lay{};
             size_t off = 0;
             lay.off_pbc = 0;
+            lay.pbc2_mode = mode;
             off = align16(sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1));
-            if (with_pbc2) {
+            if (mode == 2) {
+                lay.off_pbc2 = static_cast<uint32_t>(off);
+                off = align16(off + sizeof(double) * (static_cast<size_t>(p.S) + 1) * 64);
+            } else if (mode == 1) {
                 lay.off_pbc2 = static_cast<uint32_t>(off);
                 off = align16(off + sizeof(double) * (static_cast<size_t>(p.S) + 1) * (static_cast<size_t>(p.S) + 2) / 2);
             } else {
@@ -63,17 +74,20 @@ bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit,
             lay.off_units = static_cast<uint32_t>(off);
             off += sizeof(float) * 4 * 4 * kRow * kNarrowUnits;
             lay.off_bias = static_cast<uint32_t>(off);
-            off = align16(off + sizeof(float) * kRow * kNarrowUnits);
-            lay.off_trees = static_cast<uint32_t>(off);
-            size_t t = align16(static_cast<size_t>(p.S + 1) * p.block_stride);
-            lay.off_vterm = static_cast<uint32_t>(t);
-            t = align16(t + sizeof(double) * static_cast<size_t>(p.S + 1) * (1u << narrow_vterm_shift(p.A)));
+            off = align64(off + sizeof(float) * kRow * kNarrowUnits);
+            lay.off_trees = static_cast<uint32_t>(off);   // 64-byte aligned (descend_pair flips address bits)
+            size_t t = static_cast<size_t>(p.S + 1) * 32 * span;   // LdsTreeV<SPAN>::kBlockStride
+            lay.off_side = static_cast<uint32_t>(t);
+            t = align16(t + sizeof(SideStats) * static_cast<size_t>(p.S + 1) * span);
             lay.off_path = static_cast<uint32_t>(t);
             t = align16(t + sizeof(int32_t) * static_cast<size_t>(p.S));
             lay.off_hidden = static_cast<uint32_t>(t);
             t = align16(t + sizeof(float) * static_cast<size_t>(p.S + 1) * net.enc);
             lay.off_misc = static_cast<uint32_t>(t);
             t = align16(t + 4 * 2 * kRow);
+            lay.off_desc = static_cast<uint32_t>(t);
+            if (span == 2) t += 16 * static_cast<size_t>(p.S + 1);
+            t = align64(t);
             lay.tree_bytes = static_cast<uint32_t>(t);
             lay.waves = waves;
             lay.rows = rows;
@@ -96,7 +110,14 @@ __device__ __forceinline__ void stage_narrow_tables(const TreeParams& p, const N
         pbc[i] = p.pbc_log[i];
         pbc[p.S + 1 + i] = p.pbc_sqrt[i];
     }
-    if (lay.off_pbc2 != 0xffffffffu) {
+    if (lay.pbc2_mode == 2) {
+        // rows of 64: entry (N << 6) + n, n <= N -- the triangular table's values, addressed by shifts
+        double* pbc2 = reinterpret_cast<double*>(smem + lay.off_pbc2);
+        for (int t = tid; t < (p.S + 1) * 64; t += nthreads) {
+            const int N = t >> 6, n = t & 63;
+            if (n <= N) pbc2[t] = p.pbc_log[N] * (p.pbc_sqrt[N] / static_cast<double>(n + 1));
+        }
+    } else if (lay.pbc2_mode == 1) {
         // [N][n], n <= N: (log(..)+init) * (sqrt(N) / (n+1)) -- ucb_score's two operations (self_play.py:385-390)
         double* pbc2 = reinterpret_cast<double*>(smem + lay.off_pbc2);
         const int total = (p.S + 1) * (p.S + 2) / 2;
@@ -115,7 +136,7 @@ __device__ __forceinline__ void stage_narrow_tables(const TreeParams& p, const N
 // -------------------------------------------------------------------------------------------------
 // one launch per move: root inference + expansion + noise, S simulations, publish
 // -------------------------------------------------------------------------------------------------
-template <int SPAN, bool PBC2>
+template <int SPAN, int PBC2>
 __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void search_fused_narrow_kernel(
     TreeParams p, FcNet net, NarrowLayout lay, const float* __restrict__ weights,
     const float* __restrict__ observations,  // [E][obs]
@@ -153,8 +174,8 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     }
 
     uint8_t* region = smem + lay.off_trees + static_cast<size_t>(tree_in_block) * lay.tree_bytes;
-    const LdsTreeV tree{region, p.block_stride, p.links_offset, reinterpret_cast<double*>(region + lay.off_vterm),
-                        reinterpret_cast<int32_t*>(region + lay.off_path), SPAN == 2 ? 1 : SPAN == 4 ? 2 : SPAN == 8 ? 3 : 4};
+    const LdsTreeV<SPAN> tree{region, reinterpret_cast<SideStats*>(region + lay.off_side),
+                              reinterpret_cast<int32_t*>(region + lay.off_path)};
     float* hidden_lds = reinterpret_cast<float*>(region + lay.off_hidden);
     int32_t* root_action_lds = reinterpret_cast<int32_t*>(region + lay.off_misc);
     float* root_logit_lds = reinterpret_cast<float*>(region + lay.off_misc) + kRow;
@@ -179,8 +200,18 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         double prior[1] = {narrow_softmax(valid ? root_logit_lds[my_action] : 0.f, valid)};
         write_root_children<kRow, 1>(tree, p.A, n_root, prior, noise ? noise + static_cast<size_t>(e) * p.A : nullptr,
                                      p.noise_frac, j);
+        if constexpr (SPAN == 2) {  // the prior moves aside; the block holds table[0][0] * prior (see LdsTreeV)
+            if (j == 0) *reinterpret_cast<uint4*>(region + lay.off_desc) = uint4{0xffff00ffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (j < p.A) {
+                const double pr = tree.stats(0)[j].prior;
+                tree.side(0)[j].prior = pr;
+                tree.stats(0)[j].prior = exploration_factor<PBC2>(pbc, pbc2, p.S, 0, 0) * pr;
+            }
+        }
         group_memory_fence();
     }
+    // prior_score factor of the children of a node expanded by this search: it has one visit when they are first scored
+    const double leaf_factor = exploration_factor<PBC2>(pbc, pbc2, p.S, 1, 0);
 
     MinMax mm{INFINITY, -INFINITY};  // replicated in every lane of the row
     double root_value_sum = 0.0;     // lane 0
@@ -189,6 +220,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     uint32_t words = 0;
     int max_depth = 0;
     int64_t depth_sum = 0;
+    unsigned long long exotic = 0;   // (per wavefront) a backed-up value left normalized_value's plain range
     uint32_t* mt_key = p.mt_key + static_cast<size_t>(e) * kMtN;
     MZ_STAMP(1);
 
@@ -197,14 +229,13 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     for (int sim = 0; sim < n_sims; ++sim) {
         Descent d;
         float state;
-        if constexpr (SPAN == 2) {
-            d = descend_pair<PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, p.error_flag,
-                                   hidden_lds, enc, state);
-        } else {
-            d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, mt_key, mt_pos, words, j, group_base,
-                                        p.error_flag MZ_DSTAMP_ARGS);
-            state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
-        }
+        if constexpr (SPAN == 2)
+            d = descend_window(tree, region + lay.off_desc, sim, n_root, mm, exotic, mt_key, mt_pos, words, j, group_base,
+                               p.error_flag);
+        else
+            d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, exotic, mt_key, mt_pos, words, j,
+                                        group_base, p.error_flag MZ_DSTAMP_ARGS);
+        state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
         MZ_STAMP(2);
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
         const float x0 = (j < enc) ? state : ((j - enc == action) ? 1.f : 0.f);
@@ -215,11 +246,16 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         double prior[1] = {narrow_softmax(h.policy, j < p.A)};
         MZ_STAMP(4);
         const int k_new = sim + 1;
-        write_children<kRow, 1>(tree, k_new, p.A, prior, j);
+        if constexpr (SPAN == 2) {
+            write_pair_children(tree, k_new, p.A, prior[0], leaf_factor, j);
+            link_new_node(tree, region + lay.off_desc, d.depth, k_new, j);
+        } else {
+            write_children<kRow, 1>(tree, k_new, p.A, prior, j);
+        }
         if (j < enc) hidden_lds[k_new * enc + j] = h.norm;
         MZ_STAMP(5);
-        backup_row(tree, d.depth, sim, static_cast<double>(value_f), reward_f, two_player, p.discount, mm, root_value_sum,
-                   root_reward, j);
+        backup_row<SPAN, PBC2>(tree, d.depth, sim, static_cast<double>(value_f), reward_f, two_player, p.discount, mm,
+                               root_value_sum, root_reward, exotic, pbc, pbc2, p.S, j);
         group_memory_fence();
         if (d.depth > max_depth) max_depth = d.depth;
         depth_sum += d.depth;
@@ -252,15 +288,22 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         if (ctl.depth_sum) ctl.depth_sum[e] = static_cast<int32_t>(depth_sum);
     }
     if (ctl.visits && j < p.A) ctl.visits[static_cast<size_t>(e) * p.A + j] = (j < n_root) ? tree.links(0)[j].visits : 0;
-    // (in LDS a block is two member arrays, in HBM an array of 32-byte child records: word i of the one is stats[i] or
-    // links[i - A], word 2 c / 2 c + 1 of the other the stats / links of child c)
+    // (in LDS a block is two member arrays with the value sums apart, in HBM an array of 32-byte child records: 16-byte
+    // word 2 c / 2 c + 1 of a record block are the stats / links of child c; a child never visited has value_sum 0)
     const int block_words = 2 * p.A;
     const int n_blocks = publish_tree ? n_sims + 1 : 1;
     for (int t = j; t < n_blocks * block_words; t += kRow) {
         const int k = t / block_words, i = t - k * block_words;
-        const uint4* src = reinterpret_cast<const uint4*>(region + static_cast<size_t>(k) * p.block_stride);
         uint4* dst = reinterpret_cast<uint4*>(p.blocks + (static_cast<size_t>(k) * p.E + e) * p.line_stride);   // own line, half 0
-        dst[i < p.A ? 2 * i : 2 * (i - p.A) + 1] = src[i];
+        if (i < p.A) {
+            ChildStats st = tree.stats(k)[i];
+            const SideStats sd = tree.side(k)[i];
+            st.value_sum = tree.links(k)[i].visits > 0 ? sd.value_sum : 0.0;
+            if constexpr (SPAN == 2) st.prior = sd.prior;
+            *reinterpret_cast<ChildStats*>(dst + 2 * i) = st;
+        } else {
+            *reinterpret_cast<ChildLinks*>(dst + 2 * (i - p.A) + 1) = tree.links(k)[i - p.A];
+        }
     }
     for (int t = j; t < n_blocks * enc; t += kRow) {
         const int k = t / enc, i = t - k * enc;
@@ -341,14 +384,15 @@ static hipError_t launch_narrow_span(const TreeParams& p, const FcNet& net, cons
                       ctl, n_sims, publish_tree);
         return hipGetLastError();
     };
-    if (lay.off_pbc2 != 0xffffffffu) return go(search_fused_narrow_kernel<SPAN, true>);
-    return go(search_fused_narrow_kernel<SPAN, false>);
+    if (lay.pbc2_mode == 2) return go(search_fused_narrow_kernel<SPAN, 2>);
+    if (lay.pbc2_mode == 1) return go(search_fused_narrow_kernel<SPAN, 1>);
+    return go(search_fused_narrow_kernel<SPAN, 0>);
 }
 
 hipError_t launch_search_fused_narrow(const TreeParams& p, const FcNet& net, const NarrowLayout& lay, const float* weights,
                                       const float* observations, const MoveCtl& ctl, int n_sims, int publish_tree,
                                       hipStream_t stream, const LaunchTiming* timing) {
-    if (p.A <= 2) return launch_narrow_span<2>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
+    if (narrow_span(p.A, p.S) == 2) return launch_narrow_span<2>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
     if (p.A <= 4) return launch_narrow_span<4>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
     if (p.A <= 8) return launch_narrow_span<8>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);
     return launch_narrow_span<16>(p, net, lay, weights, observations, ctl, n_sims, publish_tree, stream, timing);

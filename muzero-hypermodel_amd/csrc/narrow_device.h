@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fc_net_device.h"
 #include "tree_device.h"
 
@@ -46,18 +48,20 @@ enum NarrowUnit : int {
 
 struct NarrowLayout {
     uint32_t off_pbc;      // double[2][S+1]
-    uint32_t off_pbc2;     // double[(S+1)(S+2)/2] or 0xffffffff
+    uint32_t off_pbc2;     // double[(S+1)(S+2)/2] (pbc2_mode 1), double[S+1][64] (mode 2) or 0xffffffff (mode 0)
     uint32_t off_units;    // float4[kNarrowUnits][4][16]
     uint32_t off_bias;     // float[kNarrowUnits][16]
     uint32_t off_trees;
     uint32_t tree_bytes;
-    uint32_t off_vterm;    // within a tree region: double[(S+1)][pow2 >= A]
+    uint32_t off_side;     // within a tree region: SideStats[(S+1)][SPAN] (SPAN = 2 for two actions, else pow2 >= max(A, 4))
     uint32_t off_path;     // int32[S]
     uint32_t off_hidden;   // float[(S+1)][enc]
     uint32_t off_misc;     // int32[16] root actions | float[16] root policy logits
+    uint32_t off_desc;     // uint8[(S+1)][16] descendant tables (two-action trees: descend_window), else unused
     uint32_t total_bytes;
     int32_t waves;         // wavefronts per workgroup
     int32_t rows;          // trees (16-lane rows) a wavefront carries: 4, or fewer to cut the wait for its deepest tree
+    int32_t pbc2_mode;     // exploration table over (N, n): 0 none, 1 triangular, 2 rows of 64 (index = N << 6 | n; S <= 63)
 };
 
 template <int R>
@@ -71,6 +75,8 @@ __device__ __forceinline__ float row_ror(float v) {
 }
 // lane i of a row receives lane i+1's value; lane 15 receives 0
 __device__ __forceinline__ int row_shl1_bits(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+// lane i of a row receives lane i-1's value; lane 0 receives 0
+__device__ __forceinline__ int row_shr1_bits(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
 __device__ __forceinline__ double row_shl1(double v) {
     const long long bits = __builtin_bit_cast(long long, v);
     const int lo = row_shl1_bits(static_cast<int>(bits & 0xffffffffll));
@@ -319,25 +325,102 @@ __device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
 }
 
 // ---- tree in LDS with the per-child value term ---------------------------------------------------------
+// A block keeps, per child c, the pair { vterm, prior } (16 bytes at c * 16: everything a score needs, one
+// ds_read_b128) and ChildLinks (16 bytes at 16 * SPAN + c * 16); SPAN = pow2 >= A is the kernel's template
+// argument, so strides are shifts and the links' distance is an instruction offset.  vterm = r + discount*(+-Q)
+// is what the backup computes for the min-max statistics; it sits where the HBM record has value_sum, and the
+// value sums (which only the backup touches) live in a side array -- the publish step puts them back.
+// With exactly two actions (SPAN == 2, the pair-wise descent) the second member is not the prior but the whole
+// prior_score = table[N][n] * prior of ucb_score, refreshed by the backup for both children of every node on the
+// path (N or n changed for exactly those) -- lane-parallel over the levels there, instead of a dependent LDS
+// round trip per level of the descent; the prior itself then sits in the side array next to the value sum.
+using lds_u8 = __attribute__((address_space(3))) uint8_t;
+using f64x2 = double __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const lds_u8*)p));
+}
+template <typename T>
+__device__ __forceinline__ T lds_load(uint32_t address) {
+    return *(const __attribute__((address_space(3))) T*)(static_cast<uintptr_t>(address));
+}
+
+struct alignas(16) SideStats {
+    double value_sum;  // Node.value_sum
+    double prior;      // Node.prior (SPAN == 2 only: elsewhere the block itself holds it)
+};
+
+constexpr int narrow_log2(int span) { return span == 2 ? 1 : span == 4 ? 2 : span == 8 ? 3 : 4; }
+
+template <int SPAN>
 struct LdsTreeV {
     static constexpr bool kInLds = true;
+    static constexpr int kShift = narrow_log2(SPAN);
+    static constexpr uint32_t kBlockStride = 32u * SPAN;
+    static constexpr uint32_t kLinksOffset = 16u * SPAN;
     uint8_t* blocks;
-    uint32_t block_stride;
-    uint32_t links_offset;
-    double* vterm_base;   // [(S+1)][1 << vterm_shift], 1 << vterm_shift = pow2 >= A
+    SideStats* side_base;  // [(S+1)][SPAN]
     int32_t* path;
-    int vterm_shift;
-    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): k <= S < 2^15, strides < 2^13
+    // (ChildStats::value_sum of an LDS block holds the child's vterm; ::prior the prior_score when SPAN == 2)
     __device__ __forceinline__ ChildStats* stats(int k) const {
-        return reinterpret_cast<ChildStats*>(blocks + __umul24(static_cast<uint32_t>(k), block_stride));
+        return reinterpret_cast<ChildStats*>(blocks + (static_cast<uint32_t>(k) << (5 + kShift)));
     }
     __device__ __forceinline__ ChildLinks* links(int k) const {
-        return reinterpret_cast<ChildLinks*>(blocks + __umul24(static_cast<uint32_t>(k), block_stride) + links_offset);
+        return reinterpret_cast<ChildLinks*>(blocks + (static_cast<uint32_t>(k) << (5 + kShift)) + kLinksOffset);
     }
-    __device__ __forceinline__ double* vterm(int k) const { return vterm_base + (k << vterm_shift); }
+    __device__ __forceinline__ SideStats* side(int k) const { return side_base + (k << kShift); }
     __device__ __forceinline__ void path_store(int level, int packed) const { path[level] = packed; }
     __device__ __forceinline__ int path_load(int level) const { return path[level]; }
 };
+
+// normalize() of MinMaxStats (self_play.py:562-566) for the children of one descent.  The quotient
+// (v - min) / (max - min) is IEEE division; the compiler's sequence for it is
+//     y = rcp(d) refined by two Newton steps;  q0 = n * y;  r = fma(-d, q0, n);  q = fma(r, y, q0)
+// wrapped in v_div_scale / v_div_fixup, which only act on operands near the ends of the exponent range.  d is the
+// same for every level of a descent, so y is computed once per simulation and a level pays the last three
+// operations.  The backups watch every value that can become v, min or max (`exotic`): while all of them are zero
+// or within 2^-400 .. 2^400, n and d are zero or within 2^-453 .. 2^401 and n <= d, where scale and fixup are the
+// identity (n == 0 gives 0 either way) -- the same bits as the division.  Otherwise the division itself runs.
+struct Normalizer {
+    double minimum, range, y;
+    bool has_range, fast;
+};
+
+__device__ __forceinline__ Normalizer make_normalizer(const MinMax& mm, unsigned long long exotic) {
+    Normalizer n;
+    n.minimum = mm.minimum;
+    n.range = mm.maximum - mm.minimum;
+    n.has_range = mm.maximum > mm.minimum;
+    n.fast = exotic == 0ull;
+    const double y0 = __builtin_amdgcn_rcp(n.range);
+    const double e0 = __builtin_fma(-n.range, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-n.range, y1, 1.0);
+    n.y = __builtin_fma(y1, e1, y1);
+    return n;
+}
+
+// (the result is discarded by the caller unless the child was visited and max > min)
+__device__ __forceinline__ double normalized_value(const Normalizer& n, double v) {
+    const double x = v - n.minimum;
+    double q;
+    if (n.fast) {
+        const double q0 = x * n.y;
+        const double r = __builtin_fma(-n.range, q0, x);
+        q = __builtin_fma(r, n.y, q0);
+    } else {
+        q = x / n.range;
+    }
+    // keep the loads and this arithmetic out of a `visits > 0` branch: they must not wait for the visit count
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// true when a value handed to the min-max statistics leaves the range normalized_value's short form is exact for
+__device__ __forceinline__ bool leaves_plain_range(double seen) {
+    const uint32_t hi = static_cast<uint32_t>(__double2hiint(seen)) & 0x7fffffffu;
+    return (hi - 0x26F00000u) > 0x32000000u && seen != 0.0;  // exponent outside 1023 - 400 .. 1023 + 400
+}
 
 // The `while node.expanded()` loop (self_play.py:321-335) with select_child / ucb_score
 // (self_play.py:364-405) for A <= SPAN <= 16 children, child c in lane c of the tree's row.
@@ -361,37 +444,42 @@ struct LdsTreeV {
 #define MZ_DSTAMP_ARGS
 #define MZ_DSTAMP(slot)
 #endif
-template <int SPAN, bool PBC2>
-__device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
-                                               int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
-                                               int32_t& mt_pos, uint32_t& words, int j, int group_base,
+
+// exploration factor of a child with n visits under a node with N: table modes 2 (rows of 64), 1 (triangular), 0 (none)
+template <int MODE>
+__device__ __forceinline__ double exploration_factor(const double* pbc, const double* pbc2, int S, int N, int n) {
+    if constexpr (MODE == 2) {
+        return pbc2[(N << 6) + n];
+    } else if constexpr (MODE == 1) {
+        return pbc2[(__mul24(N, N + 1) >> 1) + n];
+    } else {
+        const double pb = pbc[N];
+        return pb * (pbc[S + 1 + N] / static_cast<double>(n + 1));
+    }
+}
+
+template <int SPAN, int MODE>
+__device__ __forceinline__ Descent descend_row(const LdsTreeV<SPAN>& acc, const double* pbc, const double* pbc2, int S, int A,
+                                               int sim, int n_root_children, const MinMax& mm, unsigned long long exotic,
+                                               uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j, int group_base,
                                                int32_t* error_flag MZ_DSTAMP_PARAMS) {
-    const bool has_range = mm.maximum > mm.minimum;
-    const double range = mm.maximum - mm.minimum;
+    const Normalizer norm = make_normalizer(mm, exotic);
     int n_children = n_root_children;
     int k = 0, N = sim, depth = 0, slot = 0;
     for (;;) {
         const bool valid = j < n_children;
         const int c = valid ? j : 0;
-        const ChildStats* st = acc.stats(k) + c;
+        const ChildStats vp = acc.stats(k)[c];  // { vterm, prior }
         const ChildLinks* lk = acc.links(k) + c;
-        const double prior = st->prior;
+        const double prior = vp.prior;
         const int visits = lk->visits;
         const int child = lk->child_node;
-        const double vt = acc.vterm(k)[c];
+        const double vt = vp.value_sum;
         MZ_DSTAMP(8);
-        double pb;
-        if constexpr (PBC2) {
-            pb = pbc2[(__mul24(N, N + 1) >> 1) + visits];
-        } else {
-            pb = pbc[N];
-            pb = pb * (pbc[S + 1 + N] / static_cast<double>(visits + 1));
-        }
+        const double pb = exploration_factor<MODE>(pbc, pbc2, S, N, visits);
         const double prior_score = pb * prior;
-        double normalized = (vt - mm.minimum) / range;  // discarded unless visited and max > min
-        // keep the load and the division out of a `visits > 0` branch: they must not wait for the visit count
-        asm volatile("" : "+v"(normalized));
-        const double value_score = visits > 0 ? (has_range ? normalized : vt) : 0.0;
+        const double normalized = normalized_value(norm, vt);
+        const double value_score = visits > 0 ? (norm.has_range ? normalized : vt) : 0.0;
         const double score = valid ? prior_score + value_score : -INFINITY;
         MZ_DSTAMP(9);
         double best = score;
@@ -432,97 +520,127 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV& acc, const double
     return Descent{depth, k, slot};
 }
 
-// The same loop for A <= 2, software-pipelined.  Every even lane of the row plays child 0 and every odd lane
-// child 1 (eight redundant pairs: decisions are uniform over the row without any broadcast).  At the top of a
-// level a lane already holds its child's record; it immediately issues the loads of BOTH records of the block
-// that child points to -- X = the record this lane would keep if its own child is selected, Y = the record its
-// partner would need -- so the LDS round trip of the next level runs under this level's score / arg-max work
-// instead of after it.  After the selection the lane keeps X or takes its partner's Y (quad-perm DPP).
-struct ChildRecord {
-    double prior, vterm;
-    int visits, child;
-};
+// The same loop for exactly two actions (A == 2; the root may have one legal child): a WINDOW of four levels per
+// step instead of one level per step.  With one wavefront per SIMD a level of the plain loop costs its whole
+// dependent chain (load, normalize, add, compare, select: ~500 cycles); here lane h of the tree's row (h = 1..15,
+// heap order: children of h are 2h and 2h+1) looks at the node that sits at heap position h under the window's
+// root -- every node keeps a 16-byte table of the block indices of its descendants down to three levels
+// (`desc`, maintained when a node is expanded: link_new_node) -- loads that node's two child records, scores both
+// and picks the winner by itself: fifteen nodes' chains run side by side.  Two ballots (winner bit, stop bit) then
+// tell every lane the path through the window: h1 = 1, h2 = 2 h1 + W[h1], ... until a stop bit (the winner is not
+// expanded: the descent ends; or the node could not decide: a tie, which needs the tree's RNG stream, or NaN scores).
+// The lanes that turn out to sit on the path store their own path entries; the last node's block index and child
+// links reach the row through one OR-reduction.  Scores, tie lists, RNG draws and path entries are those of the
+// level-by-level loop, bit for bit: a node's decision depends on its own block and the min-max statistics only.
+// A record carries the finished prior_score (see LdsTreeV), so no table look-up sits behind the visit counts.
+// Addresses are plain LDS byte addresses: block k of the tree is at (k << 6): records at +0 / +16, links at +32 / +48.
+constexpr int kWindowAbsent = 0xff;   // desc entry: no such descendant (block indices are <= S <= 254)
 
-__device__ __forceinline__ ChildRecord load_record(const LdsTreeV& acc, int k, int c) {
-    const ChildStats* st = acc.stats(k) + c;
-    const ChildLinks* lk = acc.links(k) + c;
-    return ChildRecord{st->prior, acc.vterm(k)[c], lk->visits, lk->child_node};
+__device__ __forceinline__ uint32_t row_bits(unsigned long long ballot, bool upper_half, int shift) {
+    const uint32_t word = upper_half ? static_cast<uint32_t>(ballot >> 32) : static_cast<uint32_t>(ballot);
+    return word >> shift;   // bit h = the ballot bit of lane h of this lane's row (bits >= 16: the next row's, never read)
 }
 
-__device__ __forceinline__ ChildRecord swap_record(const ChildRecord& r) {
-    return ChildRecord{partner<1>(r.prior), partner<1>(r.vterm), partner_bits<1>(r.visits), partner_bits<1>(r.child)};
-}
-
-template <bool PBC2>
-__device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const double* pbc, const double* pbc2, int S, int A,
-                                                int sim, int n_root_children, const MinMax& mm, uint32_t* mt_key,
-                                                int32_t& mt_pos, uint32_t& words, int j, int32_t* error_flag,
-                                                const float* hidden_lds, int enc, float& parent_state) {
-    // parent_state: element j of the hidden state of the node the descent ends under -- asked for at the top
-    // of every level (the current node is the leaf's parent if this level is the last), so that the network's
-    // input is in a register when the loop ends instead of one LDS round trip later
-    const bool has_range = mm.maximum > mm.minimum;
-    const double range = mm.maximum - mm.minimum;
-    const int c = j & 1;
-    const int hidden_lane = j < enc ? j : 0;
-    int n_children = n_root_children;
-    int k = 0, N = sim, depth = 0, slot = 0;
-    ChildRecord rec = load_record(acc, 0, c < n_children ? c : 0);
+__device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const uint8_t* desc, int sim, int n_root_children,
+                                                  const MinMax& mm, unsigned long long exotic, uint32_t* mt_key,
+                                                  int32_t& mt_pos, uint32_t& words, int j, int group_base,
+                                                  int32_t* error_flag) {
+    const Normalizer norm = make_normalizer(mm, exotic);
+    const int h = j > 0 ? j : 1;   // heap position inside the window (lane 0 doubles lane 1)
+    const int my_level = h >= 8 ? 3 : h >= 4 ? 2 : h >= 2 ? 1 : 0;
+    const bool upper_half = (group_base & 32) != 0;
+    const int row_shift = group_base & 16;
+    const uint32_t blocks_address = lds_address(acc.blocks);
+    const uint32_t desc_lane = lds_address(desc) + static_cast<uint32_t>(h);
+    const bool masked_root = n_root_children < 2;   // the root's second child is not a legal action
+    int window_root = 0, depth = 0, parent = 0, slot = 0;
+    bool at_root = true;
     for (;;) {
-        const bool valid = c < n_children;
-        // this level's exploration factor first (LDS answers in order: what is needed first is asked first) ...
-        double pb;
-        if constexpr (PBC2) {
-            pb = pbc2[(__mul24(N, N + 1) >> 1) + rec.visits];
-        } else {
-            pb = pbc[N];
-            pb = pb * (pbc[S + 1 + N] / static_cast<double>(rec.visits + 1));
-        }
-        parent_state = hidden_lds[__mul24(k, enc) + hidden_lane];
-        // ... then the next level's records, both candidates: in flight while this level is scored
-        const int ck = rec.child >= 0 ? rec.child : 0;
-        const bool next_pair = A > 1;
-        const ChildRecord X = load_record(acc, ck, next_pair ? c : 0);
-        const ChildRecord Y = load_record(acc, ck, next_pair ? 1 - c : 0);
-        const double prior_score = pb * rec.prior;
-        double normalized = (rec.vterm - mm.minimum) / range;  // discarded unless visited and max > min
-        asm volatile("" : "+v"(normalized));
-        const double value_score = rec.visits > 0 ? (has_range ? normalized : rec.vterm) : 0.0;
-        const double score = valid ? prior_score + value_score : -INFINITY;
-        const double other = partner<1>(score);
-        // select_child (self_play.py:364-379) over two children
-        const bool wins = score > other, loses = other > score;
-        bool mine = wins;
-        if (!(wins || loses)) {          // (the same for every lane of the row)
-            if (score == other) {        // tie: numpy.random.choice over [0, 1]
+        // the node this lane looks at, its two child records and their links
+        const int entry = lds_load<uint8_t>(desc_lane + (static_cast<uint32_t>(window_root) << 4));
+        const int node = entry != kWindowAbsent ? entry : 0;
+        const uint32_t block = blocks_address + (static_cast<uint32_t>(node) << 6);
+        const f64x2 rec0 = lds_load<f64x2>(block), rec1 = lds_load<f64x2>(block + 16u);
+        const int visits0 = lds_load<int>(block + 36u), child0 = lds_load<int>(block + 40u);
+        const int visits1 = lds_load<int>(block + 52u), child1 = lds_load<int>(block + 56u);
+        // ucb_score of both children (self_play.py:381-405); select_child over two (self_play.py:364-379)
+        const double n0 = normalized_value(norm, rec0[0]), n1 = normalized_value(norm, rec1[0]);
+        const double score0 = rec0[1] + (visits0 > 0 ? (norm.has_range ? n0 : rec0[0]) : 0.0);
+        double score1 = rec1[1] + (visits1 > 0 ? (norm.has_range ? n1 : rec1[0]) : 0.0);
+        if (at_root && masked_root && h == 1) score1 = -INFINITY;
+        const bool second = score1 > score0;
+        const bool undecided = !second && !(score0 > score1);   // a tie, or NaN scores
+        const bool tie = score0 == score1;
+        const bool stops = undecided || (second ? child1 : child0) < 0;
+        const uint32_t winners = row_bits(__ballot(second), upper_half, row_shift);
+        const uint32_t stoppers = row_bits(__ballot(stops), upper_half, row_shift);
+        // the path through the window (the same in every lane of the row)
+        const uint32_t h1 = 2u | __builtin_amdgcn_ubfe(winners, 1u, 1u);
+        const uint32_t h2 = (h1 << 1) | __builtin_amdgcn_ubfe(winners, h1, 1u);
+        const uint32_t h3 = (h2 << 1) | __builtin_amdgcn_ubfe(winners, h2, 1u);
+        const bool stop0 = __builtin_amdgcn_ubfe(stoppers, 1u, 1u) != 0, stop1 = __builtin_amdgcn_ubfe(stoppers, h1, 1u) != 0,
+                   stop2 = __builtin_amdgcn_ubfe(stoppers, h2, 1u) != 0;
+        const int last = stop0 ? 0 : stop1 ? 1 : stop2 ? 2 : 3;   // window level of the last node of this step
+        const uint32_t h_last = stop0 ? 1u : stop1 ? h1 : stop2 ? h2 : h3;
+        const uint32_t h_mine = my_level == 0 ? 1u : my_level == 1 ? h1 : my_level == 2 ? h2 : h3;
+        const bool on_path = static_cast<uint32_t>(h) == h_mine && my_level <= last;
+        const bool is_last = static_cast<uint32_t>(h) == h_last;
+        // every node on the path but an undecided last one knows its own entry
+        if (on_path && j > 0 && !(is_last && undecided)) acc.path_store(depth + my_level, (node << 16) | (second ? 1 : 0));
+        // the last node's block index, child links and what stopped it: to every lane of the row
+        const int packed = row_or(is_last ? (node | ((child0 + 1) << 8) | ((child1 + 1) << 16) | (second ? 1 << 24 : 0) |
+                                             (undecided ? 1 << 25 : 0) | (tie ? 1 << 26 : 0))
+                                          : 0);
+        parent = packed & 0xff;
+        slot = (packed >> 24) & 1;
+        if (packed & (1 << 25)) {          // (the same for every lane of the row)
+            if (packed & (1 << 26)) {      // tie: numpy.random.choice over [0, 1]
                 int r = 0;
                 if (j == 0) r = static_cast<int>(mt_below(mt_key, &mt_pos, 2u, &words));
-                r = row_or(r);
-                mine = r == c;
-            } else {                     // NaN scores: the reference would raise; flag and take slot 0
+                slot = row_or(r);
+            } else {                       // NaN scores: the reference would raise; flag and take slot 0
                 if (j == 0) atomicOr(error_flag, 1);
-                mine = c == 0;
+                slot = 0;
             }
+            if (j == 0) acc.path_store(depth + last, (parent << 16) | slot);
         }
-        slot = mine ? c : 1 - c;
-        // (the DPP reads stay outside the conditionals: a lane that is masked off hands its partner a zero)
-        const int partner_child = partner_bits<1>(rec.child), partner_visits = partner_bits<1>(rec.visits);
-        const int sel_child = mine ? rec.child : partner_child;
-        const int sel_visits = mine ? rec.visits : partner_visits;
-        if (j == 0) acc.path_store(depth, (k << 16) | slot);
-        ++depth;
-        if (sel_child < 0) break;
+        const int next = ((packed >> (slot ? 16 : 8)) & 0xff) - 1;
+        depth += last + 1;
+        if (next < 0) break;
         if (depth > sim) {  // cannot happen on a consistent tree; guarantees every wave leaves the loop
             if (j == 0) atomicOr(error_flag, 2);
             break;
         }
-        const ChildRecord from_partner = swap_record(Y);
-        rec = mine ? X : from_partner;
-        k = sel_child;
-        N = sel_visits;
-        n_children = A;
+        window_root = next;
+        at_root = false;
     }
-    return Descent{depth, k, slot};
+    return Descent{depth, parent, slot};
+}
+
+// The descendant tables after node k_new was expanded as the child the descent ended at: the three nodes above
+// it on the path (lane t: path level depth-1-t) enter it at its heap position under them -- a leading one, then the
+// child slots from that node down to the new one.  Its own table starts with itself at position 1.
+__device__ __forceinline__ void link_new_node(const LdsTreeV<2>& acc, uint8_t* desc, int depth, int k_new, int j) {
+    const int level = depth - 1 - j;
+    const bool mine = j < 3 && level >= 0;
+    const int entry = acc.path_load(mine ? level : 0);
+    const int own = mine ? (entry & 1) << j : 0;                       // this level's slot at its place in the position
+    const int below = row_shr1_bits(own);
+    const int below2 = row_shr1_bits(below);
+    const int position = (2 << j) | own | below | below2;
+    if (mine) desc[((entry >> 16) << 4) + position] = static_cast<uint8_t>(k_new);
+    if (j == 0)
+        *reinterpret_cast<uint4*>(desc + (k_new << 4)) =
+            uint4{0xffff00ffu | (static_cast<uint32_t>(k_new) << 8), 0xffffffffu, 0xffffffffu, 0xffffffffu};
+}
+
+// children of a node of the two-action tree: { vterm (unused until visited), prior_score }, the prior aside
+__device__ __forceinline__ void write_pair_children(const LdsTreeV<2>& acc, int k, int A, double prior, double factor, int j) {
+    if (j < A) {
+        acc.stats(k)[j] = ChildStats{0.0, factor * prior};
+        acc.side(k)[j] = SideStats{0.0, prior};
+        acc.links(k)[j] = ChildLinks{0.f, 0, -1, 0};
+    }
 }
 
 // backpropagate (self_play.py:407-431) for a tree in LDS, lane = path level (16 levels per round, leaf
@@ -532,13 +650,19 @@ __device__ __forceinline__ Descent descend_pair(const LdsTreeV& acc, const doubl
 // (the division for the node's mean runs in parallel over the levels) and stores the child's value term
 // for the next descents.  min-max statistics are reduced over the row (max / min are exact under any
 // association) into every lane.  Same operations on the same operands as the sequential walk.
-__device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int sim, double value, float reward_f,
+// `exotic` collects (per wavefront) whether any value handed to the statistics left normalized_value's plain range.
+// Two-action trees (SPAN == 2): every node on the path got one more visit, so the prior_score of BOTH its children
+// changes (table row N) -- each lane refreshes the two children of its level's parent block.
+template <int SPAN, int MODE>
+__device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, int depth, int sim, double value, float reward_f,
                                            bool two_player, double discount, MinMax& mm, double& root_value_sum,
-                                           double root_reward, int j) {
+                                           double root_reward, unsigned long long& exotic, const double* pbc,
+                                           const double* pbc2, int S, int j) {
     const int k_new = sim + 1;
     double carry = value;  // value arriving at the deepest node not yet processed (uniform over the row)
     double seen_max = -INFINITY, seen_min = INFINITY;
     double into_root = 0.0;
+    bool odd = false;
     for (int base = ((depth - 1) >> 4) << 4; base >= 0; base -= kRow) {
         const int cnt = (depth - base < kRow) ? depth - base : kRow;  // levels base .. base + cnt - 1
         const int level = base + j;
@@ -549,9 +673,23 @@ __device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int s
         const int kk = packed >> 16;
         ChildStats* st = acc.stats(kk) + slot;
         ChildLinks* lk = acc.links(kk) + slot;
-        double vs = st->value_sum;
+        SideStats* sd = acc.side(kk) + slot;
+        const SideStats own = *sd;
+        double vs = own.value_sum;
         float r_f = lk->reward;
         int visits = lk->visits;
+        // two actions: the sibling's visit count and prior, and (lane 0 of a round that is not the last) the visit
+        // count of the node above this round's top level
+        int sibling_visits = 0, above_visits = 0;
+        double sibling_prior = 0.0;
+        if constexpr (SPAN == 2) {
+            sibling_visits = acc.links(kk)[1 - slot].visits;
+            sibling_prior = acc.side(kk)[1 - slot].prior;
+            if (base > 0 && j == 0) {
+                const int up = acc.path_load(base - 1);
+                above_visits = acc.links(up >> 16)[up & 0xffff].visits;
+            }
+        }
         if (leaf) {  // first visit of the new leaf: it carries the reward just predicted
             vs = 0.0;
             r_f = reward_f;
@@ -567,19 +705,28 @@ __device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int s
             val = is_top ? val : passed;
         }
         const double leaving = r_signed + discount * val;  // lane 0: the value arriving one level up
+        const int visits_new = visits + 1;
+        // visit count, after this backup, of the node whose block this lane's level sits in: the level above
+        // (the lane to the left), the root for level 0
+        int parent_visits = row_shr1_bits(visits_new);
+        if (j == 0) parent_visits = base > 0 ? above_visits + 1 : sim + 1;
         if (mine) {
             const double vs_new = vs + ((two_player && !same) ? -val : val);
-            const int visits_new = visits + 1;
             const double q = vs_new / static_cast<double>(visits_new);
             const double seen = r + discount * (two_player ? -q : q);
-            st->value_sum = vs_new;
+            sd->value_sum = vs_new;
             if (leaf)
                 *lk = ChildLinks{reward_f, 1, k_new, 2 * k_new};   // (published trees keep block k at slab k, half 0)
             else
                 lk->visits = visits_new;
-            acc.vterm(kk)[slot] = seen;
+            st->value_sum = seen;  // the vterm slot
+            if constexpr (SPAN == 2) {
+                st->prior = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, visits_new) * own.prior;
+                acc.stats(kk)[1 - slot].prior = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, sibling_visits) * sibling_prior;
+            }
             seen_max = dmax(seen_max, seen);
             seen_min = dmin(seen_min, seen);
+            odd = odd || leaves_plain_range(seen);
         }
         if (base > 0)
             carry = __shfl(leaving, 0, kRow);
@@ -600,7 +747,9 @@ __device__ __forceinline__ void backup_row(const LdsTreeV& acc, int depth, int s
         }
         seen_max = dmax(seen_max, seen);
         seen_min = dmin(seen_min, seen);
+        odd = odd || leaves_plain_range(seen);
     }
+    exotic |= __ballot(odd);
     MZ_BUTTERFLY(kRow, kRow, (seen_max = dmax(seen_max, partner<M>(seen_max)), seen_min = dmin(seen_min, partner<M>(seen_min))));
     mm.maximum = dmax(mm.maximum, seen_max);
     mm.minimum = dmin(mm.minimum, seen_min);

@@ -198,6 +198,11 @@ def fc_variant(name):
         cfg.fc_value_layers = []
         cfg.fc_policy_layers = [70]           # more neurons than 4 x 16 lanes: multi-pass phases
         cfg.support_size = 7
+    elif name == "narrow_pair_2p":
+        # exactly two actions (the pair-wise descent of the narrow kernel) with two players and masked roots
+        cfg = cartpole_config()
+        cfg.players = list(range(2))
+        cfg.num_simulations = 45
     elif name in ("narrow_2p", "narrow_1p"):
         # shapes the narrow (register-resident) kernel accepts besides cartpole's own
         cfg = cartpole_config()
@@ -219,7 +224,7 @@ def fc_variant(name):
 
 @pytest.mark.parametrize("name,group", [("tictactoe_fc", 16), ("tictactoe_fc", 0), ("connect4_fc", 16),
                                         ("cartpole_deep", 16), ("cartpole_deep", 4), ("narrow_2p", 16),
-                                        ("narrow_1p", 16)])
+                                        ("narrow_1p", 16), ("narrow_pair_2p", 16)])
 def test_fused_other_fc_shapes(eng, models_mod, oracle, name, group):
     from parity_helpers import synthetic_model
     cfg = fc_variant(name)

@@ -27,7 +27,10 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     lib_path = os.path.join(out_dir, "libmzmcts.so")
     cmd = [build._hipcc()] + build.HIPCC_FLAGS + ["-shared", "-DMZ_STAMPS", "-fno-slp-vectorize", "-o", lib_path] + build.SOURCES
-    subprocess.check_call(cmd, cwd=build.CSRC)
+    if not (os.environ.get("MZ_STAMPS_PREBUILT") and os.path.exists(lib_path)):   # (build here, measure on the GPU box)
+        subprocess.check_call(cmd, cwd=build.CSRC)
+    if os.environ.get("MZ_STAMPS_BUILD_ONLY"):
+        return
     build.LIB_PATH = lib_path
     native = importlib.import_module("muzero-hypermodel_amd._native")
     native.LIB_PATH = lib_path
