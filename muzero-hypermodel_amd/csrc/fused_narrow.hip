@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         write_root_children<kRow, 1>(tree, p.A, n_root, prior, noise ? noise + static_cast<size_t>(e) * p.A : nullptr,
                                      p.noise_frac, j);
         if constexpr (SPAN == 2) {  // the prior moves aside; the block holds table[0][0] * prior (see LdsTreeV)
-            if (j == 0) *reinterpret_cast<uint4*>(region + lay.off_desc) = uint4{0xffff00ffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (j == 0) *reinterpret_cast<uint4*>(region + lay.off_desc) = uint4{0u, 0u, 0u, 0u};   // (the root, at position 1 of its own table)
             if (j < p.A) {
                 const double pr = tree.stats(0)[j].prior;
                 tree.side(0)[j].prior = pr;
@@ -225,36 +225,46 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     MZ_STAMP(1);
 
     const ResidentWeights resident = load_resident_weights(units, bias, j);
+    int root_entry = 0;
+    if constexpr (SPAN == 2) root_entry = window_root_entry(region + lay.off_desc, j);
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
     for (int sim = 0; sim < n_sims; ++sim) {
         Descent d;
         float state;
         if constexpr (SPAN == 2)
-            d = descend_window(tree, region + lay.off_desc, sim, n_root, mm, exotic, mt_key, mt_pos, words, j, group_base,
+            d = descend_window(tree, region + lay.off_desc, root_entry, sim, n_root, mm, exotic, mt_key, mt_pos, words, j, group_base,
                                p.error_flag);
         else
             d = descend_row<SPAN, PBC2>(tree, pbc, pbc2, p.S, p.A, sim, n_root, mm, exotic, mt_key, mt_pos, words, j,
                                         group_base, p.error_flag MZ_DSTAMP_ARGS);
         state = hidden_lds[d.parent * enc + (j < enc ? j : 0)];
+        // the backup's operands (leaf-side round) and the path entries the new node is linked under: asked for here and
+        // between the layers of the network, needed after it
+        BackupRound<SPAN> round = backup_fetch_path(tree, d.depth, ((d.depth - 1) >> 4) << 4, j);
+        int link_entry = 0;
+        if constexpr (SPAN == 2) link_entry = link_fetch_path(tree, d.depth, j);
         MZ_STAMP(2);
         const int action = (d.depth == 1) ? root_action_lds[d.slot] : d.slot;
         const float x0 = (j < enc) ? state : ((j - enc == action) ? 1.f : 0.f);
-        const NarrowHeads h = narrow_recurrent(units, bias, enc, wide_support, x0, j, resident);
+        const NarrowHeads h = narrow_recurrent(
+            units, bias, enc, wide_support, x0, j, resident, [&]() { backup_fetch_records(tree, round, j); },
+            [&]() { backup_fetch_factors<SPAN, PBC2>(round, pbc, pbc2, p.S, sim, j); });
         MZ_STAMP(3);
         float value_f, reward_f;
         narrow_support_pair(h.value_a, h.value_b, h.reward_a, h.reward_b, net.F, net.support, j, value_f, reward_f);
-        double prior[1] = {narrow_softmax(h.policy, j < p.A)};
+        double prior[1] = {narrow_softmax<SPAN>(h.policy, j < p.A)};
         MZ_STAMP(4);
         const int k_new = sim + 1;
         if constexpr (SPAN == 2) {
             write_pair_children(tree, k_new, p.A, prior[0], leaf_factor, j);
-            link_new_node(tree, region + lay.off_desc, d.depth, k_new, j);
+            link_new_node(region + lay.off_desc, link_entry, d.depth, k_new, j);
+            root_entry = window_root_entry(region + lay.off_desc, j);
         } else {
             write_children<kRow, 1>(tree, k_new, p.A, prior, j);
         }
         if (j < enc) hidden_lds[k_new * enc + j] = h.norm;
         MZ_STAMP(5);
-        backup_row<SPAN, PBC2>(tree, d.depth, sim, static_cast<double>(value_f), reward_f, two_player, p.discount, mm,
+        backup_row<SPAN, PBC2>(tree, round, d.depth, sim, static_cast<double>(value_f), reward_f, two_player, p.discount, mm,
                                root_value_sum, root_reward, exotic, pbc, pbc2, p.S, j);
         group_memory_fence();
         if (d.depth > max_depth) max_depth = d.depth;

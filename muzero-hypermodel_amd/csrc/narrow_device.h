@@ -222,7 +222,8 @@ __device__ __forceinline__ float narrow_elu(float v) { return v > 0.f ? v : elu_
 __device__ __forceinline__ float narrow_rescale(float raw, int enc, int j) {
     const bool in = j < enc;
     float mn = in ? raw : INFINITY, mx = in ? raw : -INFINITY;
-    MZ_BUTTERFLY(kRow, kRow, (mn = fminf(mn, partner<M>(mn)), mx = fmaxf(mx, partner<M>(mx))));
+    const int span = enc <= 8 ? 8 : kRow;   // steps 1, 2, 4 pair lanes inside the lower half row: enough for 8 elements
+    MZ_BUTTERFLY(kRow, span, (mn = fminf(mn, partner<M>(mn)), mx = fmaxf(mx, partner<M>(mx))));
     float scale = mx - mn;
     if (scale < 1e-5f) scale += 1e-5f;
     return in ? (raw - mn) / scale : 0.f;
@@ -249,15 +250,29 @@ __device__ __forceinline__ ResidentWeights load_resident_weights(const float4* u
 
 // the remaining weights are asked for a phase ahead of their use, so that their LDS round trips run under the
 // previous phase's arithmetic (the addresses never change; only the activations are on the dependent chain)
+// after_first / after_second: work the caller wants issued behind the first / second layer of the dynamics function
+// (the fused kernel's backup asks for its tree records there, so their LDS round trips run under the network)
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <typename Hook1 = NoHook, typename Hook2 = NoHook>
 __device__ __forceinline__ NarrowHeads narrow_recurrent(const float4* units, const float* bias, int enc, bool wide_support,
-                                                        float x0, int j, const ResidentWeights& resident) {
+                                                        float x0, int j, const ResidentWeights& resident,
+                                                        Hook1 after_first = Hook1{}, Hook2 after_second = Hook2{}) {
     NarrowHeads h{};
     const UnitWeights &wd1 = resident.dyn1, &wd2 = resident.dyn2, &wr1 = resident.rew1, &wv1 = resident.val1,
                       &wp1 = resident.pol1;
     const float d1 = narrow_elu(apply_unit(wd1, x0));
+    after_first();
     const float raw = apply_unit(wd2, d1);
+    after_second();
     const UnitWeights wr2 = load_unit<kURew2a>(units, bias, j), wv2 = load_unit<kUVal2a>(units, bias, j),
                       wp2 = load_unit<kUPol2>(units, bias, j);
+    UnitWeights wr2b{}, wv2b{};
+    if (wide_support) {
+        wr2b = load_unit<kURew2b>(units, bias, j);
+        wv2b = load_unit<kUVal2b>(units, bias, j);
+    }
     h.norm = narrow_rescale(raw, enc, j);
     // the reward head reads the UN-normalised next state (models.py:157-159)
     const float r1 = narrow_elu(apply_unit(wr1, raw));
@@ -269,8 +284,8 @@ __device__ __forceinline__ NarrowHeads narrow_recurrent(const float4* units, con
     h.reward_b = 0.f;
     h.value_b = 0.f;
     if (wide_support) {
-        h.reward_b = narrow_unit<kURew2b>(units, bias, r1, j);
-        h.value_b = narrow_unit<kUVal2b>(units, bias, v1, j);
+        h.reward_b = apply_unit(wr2b, r1);
+        h.value_b = apply_unit(wv2b, v1);
     }
     return h;
 }
@@ -315,12 +330,14 @@ __device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra
 }
 
 // fp32 softmax over the lanes with valid == true (Node.expand, self_play.py:461-463), widened like .tolist()
+// SPAN: lanes 0 .. SPAN-1 hold every valid entry, and only they receive a meaningful result
+template <int SPAN = kRow>
 __device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
     float m = valid ? logit : -INFINITY;
-    MZ_BUTTERFLY(kRow, kRow, m = fmaxf(m, partner<M>(m)));
+    MZ_BUTTERFLY(SPAN, SPAN, m = fmaxf(m, partner<M>(m)));
     const float e = valid ? expf(logit - m) : 0.f;
     float s = e;
-    MZ_BUTTERFLY(kRow, kRow, s = s + partner<M>(s));
+    MZ_BUTTERFLY(SPAN, SPAN, s = s + partner<M>(s));
     return static_cast<double>(e * (1.0f / s));
 }
 
@@ -383,14 +400,16 @@ struct LdsTreeV {
 // identity (n == 0 gives 0 either way) -- the same bits as the division.  Otherwise the division itself runs.
 struct Normalizer {
     double minimum, range, y;
-    bool has_range, fast;
+    bool fast;
 };
 
+// While max <= min (MinMaxStats.normalize returns the value itself, self_play.py:563) the normalizer is (v - 0) / 1:
+// x = v, q0 = v * 1, r = fma(-1, v, v) = 0, q = fma(0, 1, v) = v -- exact, so the descent needs no second case.
 __device__ __forceinline__ Normalizer make_normalizer(const MinMax& mm, unsigned long long exotic) {
     Normalizer n;
-    n.minimum = mm.minimum;
-    n.range = mm.maximum - mm.minimum;
-    n.has_range = mm.maximum > mm.minimum;
+    const bool has_range = mm.maximum > mm.minimum;
+    n.minimum = has_range ? mm.minimum : 0.0;
+    n.range = has_range ? mm.maximum - mm.minimum : 1.0;
     n.fast = exotic == 0ull;
     const double y0 = __builtin_amdgcn_rcp(n.range);
     const double e0 = __builtin_fma(-n.range, y0, 1.0);
@@ -400,7 +419,7 @@ __device__ __forceinline__ Normalizer make_normalizer(const MinMax& mm, unsigned
     return n;
 }
 
-// (the result is discarded by the caller unless the child was visited and max > min)
+// (the result is discarded by the caller unless the child was visited)
 __device__ __forceinline__ double normalized_value(const Normalizer& n, double v) {
     const double x = v - n.minimum;
     double q;
@@ -414,6 +433,40 @@ __device__ __forceinline__ double normalized_value(const Normalizer& n, double v
     // keep the loads and this arithmetic out of a `visits > 0` branch: they must not wait for the visit count
     asm volatile("" : "+v"(q));
     return q;
+}
+
+// two values at once, the two chains side by side (one decision between the short form and the division)
+__device__ __forceinline__ void normalized_pair(const Normalizer& n, double v0, double v1, double& q0_out, double& q1_out) {
+    const double x0 = v0 - n.minimum, x1 = v1 - n.minimum;
+    double a, b;
+    if (n.fast) {
+        const double a0 = x0 * n.y, b0 = x1 * n.y;
+        const double ra = __builtin_fma(-n.range, a0, x0), rb = __builtin_fma(-n.range, b0, x1);
+        a = __builtin_fma(ra, n.y, a0);
+        b = __builtin_fma(rb, n.y, b0);
+    } else {
+        a = x0 / n.range;
+        b = x1 / n.range;
+    }
+    asm volatile("" : "+v"(a), "+v"(b));
+    q0_out = a;
+    q1_out = b;
+}
+
+// numerator / denominator with the denominator's reciprocal prepared ahead (refined_reciprocal): the last three
+// operations of the IEEE division sequence -- the same bits while the numerator is zero or within 2^-400 .. 2^400 and
+// the denominator a small positive integer (see Normalizer); the caller checks the numerator (leaves_plain_range)
+__device__ __forceinline__ double refined_reciprocal(double d) {
+    const double y0 = __builtin_amdgcn_rcp(d);
+    const double e0 = __builtin_fma(-d, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-d, y1, 1.0);
+    return __builtin_fma(y1, e1, y1);
+}
+__device__ __forceinline__ double quotient_with(double n, double d, double y) {
+    const double q0 = n * y;
+    const double r = __builtin_fma(-d, q0, n);
+    return __builtin_fma(r, y, q0);
 }
 
 // true when a value handed to the min-max statistics leaves the range normalized_value's short form is exact for
@@ -479,7 +532,7 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV<SPAN>& acc, const 
         const double pb = exploration_factor<MODE>(pbc, pbc2, S, N, visits);
         const double prior_score = pb * prior;
         const double normalized = normalized_value(norm, vt);
-        const double value_score = visits > 0 ? (norm.has_range ? normalized : vt) : 0.0;
+        const double value_score = visits > 0 ? normalized : 0.0;
         const double score = valid ? prior_score + value_score : -INFINITY;
         MZ_DSTAMP(9);
         double best = score;
@@ -534,16 +587,23 @@ __device__ __forceinline__ Descent descend_row(const LdsTreeV<SPAN>& acc, const 
 // level-by-level loop, bit for bit: a node's decision depends on its own block and the min-max statistics only.
 // A record carries the finished prior_score (see LdsTreeV), so no table look-up sits behind the visit counts.
 // Addresses are plain LDS byte addresses: block k of the tree is at (k << 6): records at +0 / +16, links at +32 / +48.
-constexpr int kWindowAbsent = 0xff;   // desc entry: no such descendant (block indices are <= S <= 254)
+// (a desc entry of 0 = no such descendant: the root is nobody's descendant; such a lane scores the root's block and is
+// never on the path)
 
 __device__ __forceinline__ uint32_t row_bits(unsigned long long ballot, bool upper_half, int shift) {
     const uint32_t word = upper_half ? static_cast<uint32_t>(ballot >> 32) : static_cast<uint32_t>(ballot);
     return word >> shift;   // bit h = the ballot bit of lane h of this lane's row (bits >= 16: the next row's, never read)
 }
 
-__device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const uint8_t* desc, int sim, int n_root_children,
-                                                  const MinMax& mm, unsigned long long exotic, uint32_t* mt_key,
-                                                  int32_t& mt_pos, uint32_t& words, int j, int group_base,
+// this lane's entry of the ROOT's descendant table: asked for by the caller as soon as the previous simulation has
+// linked its new node, a round trip ahead of the descent that needs it
+__device__ __forceinline__ int window_root_entry(const uint8_t* desc, int j) {
+    return lds_load<uint8_t>(lds_address(desc) + static_cast<uint32_t>(j > 0 ? j : 1));
+}
+
+__device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const uint8_t* desc, int root_entry, int sim,
+                                                  int n_root_children, const MinMax& mm, unsigned long long exotic,
+                                                  uint32_t* mt_key, int32_t& mt_pos, uint32_t& words, int j, int group_base,
                                                   int32_t* error_flag) {
     const Normalizer norm = make_normalizer(mm, exotic);
     const int h = j > 0 ? j : 1;   // heap position inside the window (lane 0 doubles lane 1)
@@ -553,37 +613,36 @@ __device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const 
     const uint32_t blocks_address = lds_address(acc.blocks);
     const uint32_t desc_lane = lds_address(desc) + static_cast<uint32_t>(h);
     const bool masked_root = n_root_children < 2;   // the root's second child is not a legal action
-    int window_root = 0, depth = 0, parent = 0, slot = 0;
+    int depth = 0, parent = 0, slot = 0;
+    int entry = root_entry;
     bool at_root = true;
     for (;;) {
         // the node this lane looks at, its two child records and their links
-        const int entry = lds_load<uint8_t>(desc_lane + (static_cast<uint32_t>(window_root) << 4));
-        const int node = entry != kWindowAbsent ? entry : 0;
+        const int node = entry;
         const uint32_t block = blocks_address + (static_cast<uint32_t>(node) << 6);
         const f64x2 rec0 = lds_load<f64x2>(block), rec1 = lds_load<f64x2>(block + 16u);
         const int visits0 = lds_load<int>(block + 36u), child0 = lds_load<int>(block + 40u);
         const int visits1 = lds_load<int>(block + 52u), child1 = lds_load<int>(block + 56u);
         // ucb_score of both children (self_play.py:381-405); select_child over two (self_play.py:364-379)
-        const double n0 = normalized_value(norm, rec0[0]), n1 = normalized_value(norm, rec1[0]);
-        const double score0 = rec0[1] + (visits0 > 0 ? (norm.has_range ? n0 : rec0[0]) : 0.0);
-        double score1 = rec1[1] + (visits1 > 0 ? (norm.has_range ? n1 : rec1[0]) : 0.0);
+        double n0, n1;
+        normalized_pair(norm, rec0[0], rec1[0], n0, n1);
+        const double score0 = rec0[1] + (visits0 > 0 ? n0 : 0.0);
+        double score1 = rec1[1] + (visits1 > 0 ? n1 : 0.0);
         if (at_root && masked_root && h == 1) score1 = -INFINITY;
         const bool second = score1 > score0;
         const bool undecided = !second && !(score0 > score1);   // a tie, or NaN scores
         const bool tie = score0 == score1;
-        const bool stops = undecided || (second ? child1 : child0) < 0;
         const uint32_t winners = row_bits(__ballot(second), upper_half, row_shift);
-        const uint32_t stoppers = row_bits(__ballot(stops), upper_half, row_shift);
-        // the path through the window (the same in every lane of the row)
+        const uint32_t stoppers = row_bits(__ballot(undecided) | __ballot((second ? child1 : child0) < 0), upper_half, row_shift);
+        // the path through the window (the same in every lane of the row): h_k = h3 >> (3 - k)
         const uint32_t h1 = 2u | __builtin_amdgcn_ubfe(winners, 1u, 1u);
         const uint32_t h2 = (h1 << 1) | __builtin_amdgcn_ubfe(winners, h1, 1u);
         const uint32_t h3 = (h2 << 1) | __builtin_amdgcn_ubfe(winners, h2, 1u);
-        const bool stop0 = __builtin_amdgcn_ubfe(stoppers, 1u, 1u) != 0, stop1 = __builtin_amdgcn_ubfe(stoppers, h1, 1u) != 0,
-                   stop2 = __builtin_amdgcn_ubfe(stoppers, h2, 1u) != 0;
-        const int last = stop0 ? 0 : stop1 ? 1 : stop2 ? 2 : 3;   // window level of the last node of this step
-        const uint32_t h_last = stop0 ? 1u : stop1 ? h1 : stop2 ? h2 : h3;
-        const uint32_t h_mine = my_level == 0 ? 1u : my_level == 1 ? h1 : my_level == 2 ? h2 : h3;
-        const bool on_path = static_cast<uint32_t>(h) == h_mine && my_level <= last;
+        const uint32_t stop_levels = __builtin_amdgcn_ubfe(stoppers, 1u, 1u) | (__builtin_amdgcn_ubfe(stoppers, h1, 1u) << 1) |
+                                     (__builtin_amdgcn_ubfe(stoppers, h2, 1u) << 2) | 8u;
+        const int last = __builtin_ctz(stop_levels);   // window level of the last node of this step
+        const uint32_t h_last = h3 >> (3 - last);
+        const bool on_path = static_cast<uint32_t>(h) == (h3 >> (3 - my_level)) && my_level <= last;
         const bool is_last = static_cast<uint32_t>(h) == h_last;
         // every node on the path but an undecided last one knows its own entry
         if (on_path && j > 0 && !(is_last && undecided)) acc.path_store(depth + my_level, (node << 16) | (second ? 1 : 0));
@@ -611,7 +670,7 @@ __device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const 
             if (j == 0) atomicOr(error_flag, 2);
             break;
         }
-        window_root = next;
+        entry = lds_load<uint8_t>(desc_lane + (static_cast<uint32_t>(next) << 4));
         at_root = false;
     }
     return Descent{depth, parent, slot};
@@ -620,10 +679,12 @@ __device__ __forceinline__ Descent descend_window(const LdsTreeV<2>& acc, const 
 // The descendant tables after node k_new was expanded as the child the descent ended at: the three nodes above
 // it on the path (lane t: path level depth-1-t) enter it at its heap position under them -- a leading one, then the
 // child slots from that node down to the new one.  Its own table starts with itself at position 1.
-__device__ __forceinline__ void link_new_node(const LdsTreeV<2>& acc, uint8_t* desc, int depth, int k_new, int j) {
+__device__ __forceinline__ int link_fetch_path(const LdsTreeV<2>& acc, int depth, int j) {
     const int level = depth - 1 - j;
-    const bool mine = j < 3 && level >= 0;
-    const int entry = acc.path_load(mine ? level : 0);
+    return acc.path_load(j < 3 && level >= 0 ? level : 0);
+}
+__device__ __forceinline__ void link_new_node(uint8_t* desc, int entry, int depth, int k_new, int j) {
+    const bool mine = j < 3 && depth - 1 - j >= 0;
     const int own = mine ? (entry & 1) << j : 0;                       // this level's slot at its place in the position
     const int below = row_shr1_bits(own);
     const int below2 = row_shr1_bits(below);
@@ -631,7 +692,7 @@ __device__ __forceinline__ void link_new_node(const LdsTreeV<2>& acc, uint8_t* d
     if (mine) desc[((entry >> 16) << 4) + position] = static_cast<uint8_t>(k_new);
     if (j == 0)
         *reinterpret_cast<uint4*>(desc + (k_new << 4)) =
-            uint4{0xffff00ffu | (static_cast<uint32_t>(k_new) << 8), 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            uint4{static_cast<uint32_t>(k_new) << 8, 0u, 0u, 0u};
 }
 
 // children of a node of the two-action tree: { vterm (unused until visited), prior_score }, the prior aside
@@ -653,51 +714,112 @@ __device__ __forceinline__ void write_pair_children(const LdsTreeV<2>& acc, int 
 // `exotic` collects (per wavefront) whether any value handed to the statistics left normalized_value's plain range.
 // Two-action trees (SPAN == 2): every node on the path got one more visit, so the prior_score of BOTH its children
 // changes (table row N) -- each lane refreshes the two children of its level's parent block.
+//
+// Nothing a round reads depends on the value being backed up, and with one wavefront per SIMD a wait for LDS is
+// idle time: the fused kernel asks for the leaf-side round's operands in three steps placed between the layers of
+// the network (path entry -> records -> exploration factors), each step's answers landing under the next layer.
+template <int SPAN>
+struct BackupRound {
+    int base, cnt;
+    bool mine, leaf;
+    int packed;                        // path entry of this lane's level
+    SideStats own;                     // { value_sum, prior } of the child the path took
+    float reward;
+    int visits;
+    int sibling_visits, above_visits;  // two actions only
+    double sibling_prior;
+    int visits_new, parent_visits;
+    double factor_own, factor_sibling; // table[parent_visits][visits_new / sibling_visits]
+    double visits_new_f, visits_new_reciprocal;
+};
+
+template <int SPAN>
+__device__ __forceinline__ BackupRound<SPAN> backup_fetch_path(const LdsTreeV<SPAN>& acc, int depth, int base, int j) {
+    BackupRound<SPAN> r{};
+    r.base = base;
+    r.cnt = (depth - base < kRow) ? depth - base : kRow;  // levels base .. base + cnt - 1
+    r.mine = j < r.cnt;
+    r.leaf = base + j == depth - 1;
+    r.packed = acc.path_load(r.mine ? base + j : base);
+    if constexpr (SPAN == 2) {
+        // (lane 0 of a round that is not the last: the node above this round's top level, for its visit count)
+        if (base > 0 && j == 0) r.above_visits = acc.path_load(base - 1);
+    }
+    return r;
+}
+
+template <int SPAN>
+__device__ __forceinline__ void backup_fetch_records(const LdsTreeV<SPAN>& acc, BackupRound<SPAN>& r, int j) {
+    const int slot = r.packed & 0xffff;
+    const int kk = r.packed >> 16;
+    const ChildLinks* lk = acc.links(kk) + slot;
+    r.own = acc.side(kk)[slot];
+    r.reward = lk->reward;
+    r.visits = lk->visits;
+    if constexpr (SPAN == 2) {
+        r.sibling_visits = acc.links(kk)[1 - slot].visits;
+        r.sibling_prior = acc.side(kk)[1 - slot].prior;
+        if (r.base > 0 && j == 0) {
+            const int up = r.above_visits;
+            r.above_visits = acc.links(up >> 16)[up & 0xffff].visits;
+        }
+    }
+}
+
 template <int SPAN, int MODE>
-__device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, int depth, int sim, double value, float reward_f,
-                                           bool two_player, double discount, MinMax& mm, double& root_value_sum,
-                                           double root_reward, unsigned long long& exotic, const double* pbc,
-                                           const double* pbc2, int S, int j) {
+__device__ __forceinline__ void backup_fetch_factors(BackupRound<SPAN>& r, const double* pbc, const double* pbc2, int S,
+                                                     int sim, int j) {
+    if (r.leaf) r.visits = 0;   // first visit of the new leaf
+    r.visits_new = r.visits + 1;
+    r.visits_new_f = static_cast<double>(r.visits_new);
+    r.visits_new_reciprocal = refined_reciprocal(r.visits_new_f);
+    if constexpr (SPAN == 2) {
+        // visit count, after this backup, of the node whose block this lane's level sits in: the level above
+        // (the lane to the left), the root for level 0
+        int parent_visits = row_shr1_bits(r.visits_new);
+        if (j == 0) parent_visits = r.base > 0 ? r.above_visits + 1 : sim + 1;
+        r.parent_visits = parent_visits;
+        if (r.mine) {
+            r.factor_own = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, r.visits_new);
+            r.factor_sibling = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, r.sibling_visits);
+        }
+    }
+}
+
+// `first`: the leaf-side round, already fetched (backup_fetch_*); deeper paths fetch their further rounds in place
+template <int SPAN, int MODE>
+__device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, const BackupRound<SPAN>& first, int depth, int sim,
+                                           double value, float reward_f, bool two_player, double discount, MinMax& mm,
+                                           double& root_value_sum, double root_reward, unsigned long long& exotic,
+                                           const double* pbc, const double* pbc2, int S, int j) {
     const int k_new = sim + 1;
+    // (the root's division, prepared before the value arrives)
+    const double root_visits = static_cast<double>(sim + 1);
+    const double root_visits_reciprocal = refined_reciprocal(root_visits);
     double carry = value;  // value arriving at the deepest node not yet processed (uniform over the row)
     double seen_max = -INFINITY, seen_min = INFINITY;
     double into_root = 0.0;
     bool odd = false;
-    for (int base = ((depth - 1) >> 4) << 4; base >= 0; base -= kRow) {
-        const int cnt = (depth - base < kRow) ? depth - base : kRow;  // levels base .. base + cnt - 1
-        const int level = base + j;
-        const bool mine = j < cnt;
-        const bool leaf = level == depth - 1;
-        const int packed = acc.path_load(mine ? level : base);
-        const int slot = packed & 0xffff;
-        const int kk = packed >> 16;
+    BackupRound<SPAN> r = first;
+    for (;;) {
+        const int cnt = r.cnt;
+        const int level = r.base + j;
+        const bool mine = r.mine;
+        const bool leaf = r.leaf;
+        const int slot = r.packed & 0xffff;
+        const int kk = r.packed >> 16;
         ChildStats* st = acc.stats(kk) + slot;
         ChildLinks* lk = acc.links(kk) + slot;
         SideStats* sd = acc.side(kk) + slot;
-        const SideStats own = *sd;
-        double vs = own.value_sum;
-        float r_f = lk->reward;
-        int visits = lk->visits;
-        // two actions: the sibling's visit count and prior, and (lane 0 of a round that is not the last) the visit
-        // count of the node above this round's top level
-        int sibling_visits = 0, above_visits = 0;
-        double sibling_prior = 0.0;
-        if constexpr (SPAN == 2) {
-            sibling_visits = acc.links(kk)[1 - slot].visits;
-            sibling_prior = acc.side(kk)[1 - slot].prior;
-            if (base > 0 && j == 0) {
-                const int up = acc.path_load(base - 1);
-                above_visits = acc.links(up >> 16)[up & 0xffff].visits;
-            }
-        }
+        double vs = r.own.value_sum;
+        float r_f = r.reward;
         if (leaf) {  // first visit of the new leaf: it carries the reward just predicted
             vs = 0.0;
             r_f = reward_f;
-            visits = 0;
         }
-        const double r = static_cast<double>(r_f);
+        const double rw = static_cast<double>(r_f);
         const bool same = ((depth - (level + 1)) & 1) == 0;  // node.to_play == to_play of the leaf
-        const double r_signed = two_player ? (same ? -r : r) : r;
+        const double r_signed = two_player ? (same ? -rw : rw) : rw;
         double val = carry;
         const bool is_top = j >= cnt - 1;
         for (int s = cnt - 1; s > 0; --s) {
@@ -705,46 +827,46 @@ __device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, int depth,
             val = is_top ? val : passed;
         }
         const double leaving = r_signed + discount * val;  // lane 0: the value arriving one level up
-        const int visits_new = visits + 1;
-        // visit count, after this backup, of the node whose block this lane's level sits in: the level above
-        // (the lane to the left), the root for level 0
-        int parent_visits = row_shr1_bits(visits_new);
-        if (j == 0) parent_visits = base > 0 ? above_visits + 1 : sim + 1;
         if (mine) {
             const double vs_new = vs + ((two_player && !same) ? -val : val);
-            const double q = vs_new / static_cast<double>(visits_new);
-            const double seen = r + discount * (two_player ? -q : q);
+            double q = quotient_with(vs_new, r.visits_new_f, r.visits_new_reciprocal);
+            if (__ballot(leaves_plain_range(vs_new)) != 0ull) q = vs_new / r.visits_new_f;   // (per wavefront; never seen)
+            const double seen = rw + discount * (two_player ? -q : q);
             sd->value_sum = vs_new;
             if (leaf)
                 *lk = ChildLinks{reward_f, 1, k_new, 2 * k_new};   // (published trees keep block k at slab k, half 0)
             else
-                lk->visits = visits_new;
+                lk->visits = r.visits_new;
             st->value_sum = seen;  // the vterm slot
             if constexpr (SPAN == 2) {
-                st->prior = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, visits_new) * own.prior;
-                acc.stats(kk)[1 - slot].prior = exploration_factor<MODE>(pbc, pbc2, S, parent_visits, sibling_visits) * sibling_prior;
+                st->prior = r.factor_own * r.own.prior;
+                acc.stats(kk)[1 - slot].prior = r.factor_sibling * r.sibling_prior;
             }
             seen_max = dmax(seen_max, seen);
             seen_min = dmin(seen_min, seen);
             odd = odd || leaves_plain_range(seen);
         }
-        if (base > 0)
-            carry = __shfl(leaving, 0, kRow);
-        else
+        if (r.base == 0) {
             into_root = leaving;
+            break;
+        }
+        carry = __shfl(leaving, 0, kRow);
+        r = backup_fetch_path(acc, depth, r.base - kRow, j);
+        backup_fetch_records(acc, r, j);
+        backup_fetch_factors<SPAN, MODE>(r, pbc, pbc2, S, sim, j);
     }
     // root (tree depth 0)
     if (j == 0) {
-        const double n_root = static_cast<double>(sim + 1);
         double seen;
         if (!two_player) {
             root_value_sum += into_root;
-            seen = root_reward + discount * (root_value_sum / n_root);
         } else {
             const bool same = (depth & 1) == 0;
             root_value_sum += same ? into_root : -into_root;
-            seen = root_reward + discount * -(root_value_sum / n_root);
         }
+        double mean = quotient_with(root_value_sum, root_visits, root_visits_reciprocal);
+        if (leaves_plain_range(root_value_sum)) mean = root_value_sum / root_visits;
+        seen = root_reward + discount * (two_player ? -mean : mean);
         seen_max = dmax(seen_max, seen);
         seen_min = dmin(seen_min, seen);
         odd = odd || leaves_plain_range(seen);
