@@ -61,6 +61,7 @@ bool plan_narrow_layout(const TreeParams& p, const FcNet& net, size_t lds_limit,
             size_t off = 0;
             lay.off_pbc = 0;
             lay.pbc2_mode = mode;
+            if (const char* env = std::getenv("MZMCTS_NARROW_EXACT_DIV")) lay.exact_division = std::atoi(env) != 0;
             off = align16(sizeof(double) * 2 * (static_cast<size_t>(p.S) + 1));
             if (mode == 2) {
                 lay.off_pbc2 = static_cast<uint32_t>(off);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     uint32_t words = 0;
     int max_depth = 0;
     int64_t depth_sum = 0;
-    unsigned long long exotic = 0;   // (per wavefront) a backed-up value left normalized_value's plain range
+    unsigned long long exotic = lay.exact_division ? 1ull : 0ull;   // (per wavefront) a backed-up value left normalized_value's plain range
     uint32_t* mt_key = p.mt_key + static_cast<size_t>(e) * kMtN;
     MZ_STAMP(1);
 

@@ -62,6 +62,8 @@ struct NarrowLayout {
     int32_t waves;         // wavefronts per workgroup
     int32_t rows;          // trees (16-lane rows) a wavefront carries: 4, or fewer to cut the wait for its deepest tree
     int32_t pbc2_mode;     // exploration table over (N, n): 0 none, 1 triangular, 2 rows of 64 (index = N << 6 | n; S <= 63)
+    int32_t exact_division; // != 0: every quotient by the division itself (MZMCTS_NARROW_EXACT_DIV=1; the tests' A/B of the
+                           // reciprocal-prepared forms, see Normalizer)
 };
 
 template <int R>
@@ -830,7 +832,7 @@ __device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, const Back
         if (mine) {
             const double vs_new = vs + ((two_player && !same) ? -val : val);
             double q = quotient_with(vs_new, r.visits_new_f, r.visits_new_reciprocal);
-            if (__ballot(leaves_plain_range(vs_new)) != 0ull) q = vs_new / r.visits_new_f;   // (per wavefront; never seen)
+            if ((exotic | __ballot(leaves_plain_range(vs_new))) != 0ull) q = vs_new / r.visits_new_f;   // (per wavefront; never seen)
             const double seen = rw + discount * (two_player ? -q : q);
             sd->value_sum = vs_new;
             if (leaf)
@@ -865,7 +867,7 @@ __device__ __forceinline__ void backup_row(const LdsTreeV<SPAN>& acc, const Back
             root_value_sum += same ? into_root : -into_root;
         }
         double mean = quotient_with(root_value_sum, root_visits, root_visits_reciprocal);
-        if (leaves_plain_range(root_value_sum)) mean = root_value_sum / root_visits;
+        if (exotic != 0ull || leaves_plain_range(root_value_sum)) mean = root_value_sum / root_visits;
         seen = root_reward + discount * (two_player ? -mean : mean);
         seen_max = dmax(seen_max, seen);
         seen_min = dmin(seen_min, seen);

@@ -103,6 +103,40 @@ def test_fused_equals_lockstep_bit_for_bit(eng, models_mod, group, hidden_in_lds
         assert np.array_equal(a_pool, b_pool)   # every hidden state of every tree
 
 
+@pytest.mark.parametrize("table_mode,exact_division", [(2, 0), (2, 1), (1, 0), (0, 0), (0, 1)])
+def test_narrow_kernel_forms_are_bit_identical(eng, models_mod, monkeypatch, table_mode, exact_division):
+    """The narrow kernel's short forms against the plain ones, through the lock-step search: the exploration table in
+    rows of 64 / triangular / not at all (MZMCTS_NARROW_PBC2), and every quotient (normalisation, node means) by the
+    reciprocal-prepared last three operations of the division sequence or by the division itself
+    (MZMCTS_NARROW_EXACT_DIV): same visit counts, value sums, min-max bounds, trees and hidden states."""
+    config = cartpole_config()
+    model, _ = cartpole_model_and_weights(models_mod, config, "cuda")
+    fx = load_golden("g4_cartpole_traces")
+    T = len(fx["seed"])
+    E = 3 * T - 5
+    seeds = ([int(s) for s in fx["seed"]] * 3)[:E]
+    obs = np.concatenate([fx["obs"]] * 3)[:E]
+    legal, to_play = [[0, 1]] * E, [0] * E
+    monkeypatch.setenv("MZMCTS_NARROW_PBC2", str(table_mode))
+    monkeypatch.setenv("MZMCTS_NARROW_EXACT_DIV", str(exact_division))
+    results = []
+    for fused in (False, True):
+        engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=16)
+        engine.configure_fused_fc(model)
+        engine.set_fused_options("narrow")
+        run = engine.search_fused if fused else engine.search_lockstep_fc
+        st = copy_stats(run(torch.from_numpy(obs), legal, to_play, True))
+        results.append((st, engine.export_tree(E - 1), engine.export_tree(0), engine.pool.clone().cpu().numpy()))
+        engine.close()
+    (a_st, a_t1, a_t0, a_pool), (b_st, b_t1, b_t0, b_pool) = results
+    for key in a_st:
+        assert np.array_equal(a_st[key], b_st[key]), key
+    for a_tree, b_tree in ((a_t1, b_t1), (a_t0, b_t0)):
+        for key in a_tree:
+            assert np.array_equal(a_tree[key], b_tree[key]), f"tree {key}"
+    assert np.array_equal(a_pool, b_pool)
+
+
 @pytest.mark.parametrize("group,variant", [(4, "generic"), (16, "narrow")])
 def test_fused_vs_reference_traces(eng, models_mod, group, variant):
     config = cartpole_config()
