@@ -361,6 +361,19 @@ int mzmcts_moves_inputs_ring(mzmcts_engine *engine, void **host_base, int64_t *m
 int mzmcts_affine_act(const float *x, const float *scale, const float *shift, const float *residual, float *out,
                       int64_t count, int32_t channels, int32_t plane, int32_t relu, void *stream);
 
+/* The CNN down-sampler of the representation network in inference mode (models.py:278-297 DownsampleCNN, called from
+ * models.py:318-327): Conv2d(channels, mid, kernel1, stride 4, padding 2) -> ReLU -> MaxPool2d(3, 2) -> Conv2d(mid, cout, 5,
+ * padding 2) -> ReLU -> MaxPool2d(3, 2) -> AdaptiveAvgPool2d((out_h, out_w)), one launch, both convolutions on the fp32 matrix
+ * cores (exact fp32 products and sums; the order of the sums differs from the convolution library's).
+ *   x dev f32[batch, channels, height, width] (16-byte aligned), w1 dev f32[mid, channels, kernel1, kernel1] (16-byte aligned),
+ *   b1 dev f32[mid], w2 dev f32[cout, mid, 5, 5], b2 dev f32[cout], out dev f32[batch, cout, out_h, out_w].
+ * Covered: 4 x 84 x 84 frames, kernel1 = 12, mid <= 16, cout <= 16, out_h, out_w <= 8 (BASELINE config #5).
+ * MZMCTS_ERR_INVALID when the shape is not covered: the caller keeps its convolution library.  No allocation, no
+ * synchronisation. */
+int mzmcts_downsample_cnn(const float *x, int64_t batch, int32_t channels, int32_t height, int32_t width, const float *w1,
+                          const float *b1, int32_t mid, int32_t kernel1, const float *w2, const float *b2, int32_t cout,
+                          int32_t out_h, int32_t out_w, float *out, void *stream);
+
 /* The dynamics network's input (models.py:553-568): out[b] = state[b]'s `channels` planes followed by one plane
  * filled with action[b] / action_space.  state dev f32[batch, channels, plane], action dev i64[batch],
  * out dev f32[batch, channels + 1, plane]; batch <= 65535.  One launch for torch's cast, division and cat;

@@ -149,6 +149,9 @@ PROTOTYPES = {
     "mzmcts_board_tower_gathered": (ctypes.c_int, [ctypes.POINTER(MzTowerGather), ctypes.c_int64] + [ctypes.c_int32] * 5 +
                                     [c_void, ctypes.c_int32, c_void]),
     "mzmcts_board_tower_split": (ctypes.c_int, [c_void, ctypes.c_int64] + [ctypes.c_int32] * 5 + [c_void, ctypes.c_int32, c_void]),
+    "mzmcts_downsample_cnn": (ctypes.c_int, [c_void, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void, c_void,
+                                             ctypes.c_int32, ctypes.c_int32, c_void, c_void, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, c_void, c_void]),
     "mzmcts_affine_act": (ctypes.c_int, [c_void] * 5 + [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void]),
     # include/mzenv.h
     "mzenv_advance": (ctypes.c_int, [c_void] * 10),

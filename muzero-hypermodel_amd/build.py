@@ -10,7 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmzmcts.so")
-SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "mzmcts_moves.hip", "mzmcts_rng.hip", "mzhist.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip", "board_conv.hip", "trainer_kernels.hip"]
+SOURCES = ["mcts_kernels.hip", "fused_narrow.hip", "mzmcts_capi.hip", "mzmcts_moves.hip", "mzmcts_rng.hip", "mzhist.hip", "env_kernels.hip", "mzenv_capi.hip", "mzreplay.hip", "net_kernels.hip", "board_conv.hip", "downsample_cnn.hip", "trainer_kernels.hip"]
 HEADERS = ["engine_host.h", "np_legacy_rng.h", "glibc_libm.h", "glibc_libm_tables.inc", "tree_layout.h", "tree_device.h", "fc_net_device.h", "narrow_device.h", "kernel_common.h", "env_layout.h", os.path.join("..", "..", "include", "mzmcts.h"),
            os.path.join("..", "..", "include", "mzenv.h"), os.path.join("..", "..", "include", "mzreplay.h"), os.path.join("..", "..", "include", "mzhist.h"), os.path.join("..", "..", "include", "mztrain.h")]
 

@@ -621,6 +621,9 @@ class DownsampleCNN(torch.nn.Module):
 
     def forward(self, x):
         if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            out = self._native_forward(x)
+            if out is not None:
+                return out
             # MIOpen's immediate mode falls back to a per-image im2col + GEMM loop for these shapes (12 x 12 kernel, stride
             # 4 on 84 x 84 frames): two launches per image, 57 % of the GPU time of an Atari-like search at 1024 envs
             # (profiles/r02_bench_atari84_kernel_stats.csv).  Letting it search once per shape picks a batched solver
@@ -628,6 +631,31 @@ class DownsampleCNN(torch.nn.Module):
             with torch.backends.cudnn.flags(enabled=True, benchmark=True):
                 return self.avgpool(self.features(x))
         return self.avgpool(self.features(x))
+
+
+    def _native_forward(self, x):
+        """The seven layers in one HIP launch (include/mzmcts.h mzmcts_downsample_cnn; both convolutions on the fp32
+        matrix cores).  None when the shape is not covered (anything but config #5's 4 x 84 x 84 frames) or
+        MZ_DOWNSAMPLE=torch asks for the convolution library."""
+        conv1, conv2 = self.features[0], self.features[3]
+        if (os.environ.get("MZ_DOWNSAMPLE", "") == "torch" or x.dtype != torch.float32 or x.dim() != 4
+                or conv1.stride != (4, 4) or conv1.padding != (2, 2) or conv2.kernel_size != (5, 5) or conv2.padding != (2, 2)
+                or conv1.bias is None or conv2.bias is None):
+            return None
+        x = x.contiguous()
+        h, w = self.avgpool.output_size
+        out = torch.empty((x.shape[0], conv2.out_channels, h, w), dtype=torch.float32, device=x.device)
+        w1, w2 = conv1.weight.contiguous(), conv2.weight.contiguous()
+        with torch.cuda.device(x.device):
+            rc = _native.load().mzmcts_downsample_cnn(
+                x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], x.shape[3], w1.data_ptr(), conv1.bias.data_ptr(),
+                conv1.out_channels, conv1.kernel_size[0], w2.data_ptr(), conv2.bias.data_ptr(), conv2.out_channels, h, w,
+                out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc == -1:        # MZMCTS_ERR_INVALID: not this launch's shape
+            return None
+        if rc != 0:
+            raise RuntimeError(f"mzmcts_downsample_cnn failed ({rc}) on frames of shape {tuple(x.shape)}")
+        return out
 
 
 class RepresentationNetwork(torch.nn.Module):

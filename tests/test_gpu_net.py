@@ -339,3 +339,39 @@ def test_board_column_heads_are_bit_identical_to_the_mfma_heads(pkg, monkeypatch
         assert torch.equal(a, b)
     for got, ref in zip(out["on"][:3], want):
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch,mid_out", [(5, (10, 16)), (300, (10, 16)), (3, (7, 12))])
+def test_downsample_cnn_launch_equals_the_torch_layers(pkg, monkeypatch, batch, mid_out):
+    """include/mzmcts.h mzmcts_downsample_cnn (the seven layers of models.py:278-297 in one launch, config #5's 4 x 84 x 84
+    frames) against the same layers in float64 on the CPU and against the convolution library's float32 path: the kernel's
+    products and sums are exact fp32 operations in its own order, so it must sit as close to the float64 result as the
+    library does (within rounding of a 576-term fp32 sum)."""
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    torch.manual_seed(batch)
+    mid, cout = mid_out
+    net = models.DownsampleCNN(4, 2 * mid - 4, (6, 6))          # mid = (in + out) // 2
+    assert net.features[0].out_channels == mid
+    net.features[3] = torch.nn.Conv2d(mid, cout, kernel_size=5, padding=2)
+    net = net.cuda().eval()
+    x = torch.rand((batch, 4, 84, 84), device="cuda")
+    x[0, 1, 40:44, 40:44] = -3.0                               # negative pre-activations somewhere
+    with torch.no_grad():
+        got = net(x)
+        monkeypatch.setenv("MZ_DOWNSAMPLE", "torch")
+        library = net(x)
+        monkeypatch.delenv("MZ_DOWNSAMPLE")
+        exact = net.double().cpu()(x[: min(batch, 8)].double().cpu())
+        net.float().cuda()
+    assert got.shape == (batch, cout, 6, 6) and got.dtype == torch.float32
+    g, l, e = got[: exact.shape[0]].double().cpu(), library[: exact.shape[0]].double().cpu(), exact
+    scale = e.abs().max().item()
+    err_kernel, err_library = (g - e).abs().max().item(), (l - e).abs().max().item()
+    assert err_kernel <= 2e-6 * scale + 1e-7, (err_kernel, err_library, scale)
+    assert torch.allclose(got, library, rtol=2e-5, atol=2e-6 * scale)
+    # a NaN in a frame reaches that frame's outputs and no other frame's
+    x[1, 0, 10, 10] = float("nan")
+    with torch.no_grad():
+        poisoned = net(x)
+    assert torch.isnan(poisoned[1]).any() and not torch.isnan(poisoned[0]).any()
+    assert torch.equal(poisoned[0], got[0]) and torch.equal(poisoned[2:], got[2:])
