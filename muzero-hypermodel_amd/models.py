@@ -978,9 +978,49 @@ class MuZeroResidualNetwork(AbstractNetwork):
         raw, reward = self.dynamics_network(x)
         return board_rescale(raw, out=out_state), reward
 
+    def _root_tower(self, observation):
+        """representation (stem or down-sampler + residual blocks) + rescale + prediction blocks of initial_inference
+        (models.py:604-616, 318-335, 525-549) as one tower launch -- the shape of _recurrent_tower without the action
+        plane: a network that starts with a residual block takes its first skip connection from the tower's input.
+        Returns (encoded state, prediction features) or None when the launch does not apply (MZ_ROOT_TOWER=off, training,
+        shapes the towers do not cover): the caller takes the per-layer path."""
+        if os.environ.get("MZ_ROOT_TOWER", "on") == "off" or not observation.is_cuda or self.training or torch.is_grad_enabled():
+            return None
+        rep, pred = self.representation_network.module, self.prediction_network.module
+        if rep.downsample:
+            x = rep.downsample_net(observation)
+            layers = []
+        else:
+            x = observation
+            layers = [(rep.conv, rep.bn, 1, 0)]
+        layers += self._block_layers(rep.resblocks)
+        if not layers or x.dim() != 4:
+            return None
+        last_rep = len(layers) - 1
+        layers += self._block_layers(pred.resblocks)
+        c = layers[0][0].out_channels
+        if c == 64:
+            return None     # (the root of a 64-channel network keeps the exact-fp32 per-layer kernels, not the split tower)
+        b, _, h, w = x.shape
+        state = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+        features = torch.empty_like(state) if len(layers) - 1 > last_rep else None
+        exports = {last_rep: (None, state)}
+        if features is not None:
+            exports[len(layers) - 1] = (features, None)
+        if not self._tower(x, layers, exports):
+            return None
+        return state, features if features is not None else state
+
     def initial_inference(self, observation):
-        encoded_state = self.representation(observation)
-        policy_logits, value = self.prediction(encoded_state)
+        fused = self._root_tower(observation)
+        if fused is not None:
+            encoded_state, features = fused
+            pred = self.prediction_network.module
+            value, policy_logits = conv_heads(features, [(pred.conv1x1_value, pred.fc_value, pred.block_output_size_value),
+                                                         (pred.conv1x1_policy, pred.fc_policy, pred.block_output_size_policy)])
+        else:
+            encoded_state = self.representation(observation)
+            policy_logits, value = self.prediction(encoded_state)
         reward = self._zero_reward_logits(observation.shape[0], observation.device)
         return value, reward, policy_logits, encoded_state
 

@@ -375,3 +375,35 @@ def test_downsample_cnn_launch_equals_the_torch_layers(pkg, monkeypatch, batch, 
         poisoned = net(x)
     assert torch.isnan(poisoned[1]).any() and not torch.isnan(poisoned[0]).any()
     assert torch.equal(poisoned[0], got[0]) and torch.equal(poisoned[2:], got[2:])
+
+
+@pytest.mark.parametrize("game", ["tictactoe", "atari84"])
+def test_root_tower_equals_the_per_layer_root(pkg, monkeypatch, game):
+    """initial_inference with representation blocks + rescale + prediction blocks in one tower launch
+    (models.MuZeroResidualNetwork._root_tower: a tower that may START with a residual block, whose first skip connection
+    is the tower's input) against the per-layer path (MZ_ROOT_TOWER=off): exact fp32 products and sums in both, in
+    different orders."""
+    from parity_helpers import synthetic_model
+    models = importlib.import_module("muzero-hypermodel_amd.models")
+    if game == "atari84":
+        config = importlib.import_module("muzero-hypermodel_amd.games.breakout").atari84_config()
+    else:
+        config = importlib.import_module(f"muzero-hypermodel_amd.games.{game}").MuZeroConfig()
+    model, _ = synthetic_model(models, config, "cuda", seed=5)
+    torch.manual_seed(3)
+    batch = 77
+    c, h, w = config.observation_shape
+    obs = torch.rand((batch, c, h, w), device="cuda") if game == "atari84" else \
+        torch.randint(0, 2, (batch, c, h, w), device="cuda").float()
+    with torch.no_grad():
+        assert model._root_tower(obs) is not None
+        got = model.initial_inference(obs)
+        monkeypatch.setenv("MZ_ROOT_TOWER", "off")
+        assert model._root_tower(obs) is None
+        want = model.initial_inference(obs)
+    for g, w_, name in zip(got, want, ("value", "reward", "policy", "state")):
+        assert g.shape == w_.shape, name
+        scale = max(w_[torch.isfinite(w_)].abs().max().item(), 1.0)
+        finite = torch.isfinite(w_)
+        assert torch.equal(torch.isfinite(g), finite), name
+        assert (g[finite] - w_[finite]).abs().max().item() <= 2e-5 * scale, name
