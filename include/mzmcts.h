@@ -57,7 +57,9 @@ typedef struct mzmcts_config {
     int32_t hidden_floats;   /* H: fp32 values per hidden state (0 = engine keeps no states)  */
     int32_t device;          /* HIP device ordinal                                            */
     int32_t group_width;     /* lanes of a wavefront per tree: 0 = auto (pow2 >= min(A,64)); or a power of two
-                                in [auto, 64] to give each tree more lanes (fused FC search)           */
+                                in [auto, 64] to give each tree more lanes (fused FC search); or auto / 2
+                                (4 or 8, when A > auto / 2): two children per lane, half the wavefronts of
+                                the tree kernels; or 1 when A == 2                                     */
     double discount;                  /* config.discount                                      */
     double pb_c_base;                 /* config.pb_c_base                                     */
     double pb_c_init;                 /* config.pb_c_init                                     */

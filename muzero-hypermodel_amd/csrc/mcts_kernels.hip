@@ -912,8 +912,12 @@ static void dispatch_group(const TreeParams& p, Fn&& fn) {
             if (p.chunks == 2) fn(IntC<1>{}, IntC<2>{}); else fn(IntC<1>{}, IntC<1>{});
             break;
         case 2: fn(IntC<2>{}, IntC<1>{}); break;
-        case 4: fn(IntC<4>{}, IntC<1>{}); break;
-        case 8: fn(IntC<8>{}, IntC<1>{}); break;
+        case 4:
+            if (p.chunks == 2) fn(IntC<4>{}, IntC<2>{}); else fn(IntC<4>{}, IntC<1>{});
+            break;
+        case 8:
+            if (p.chunks == 2) fn(IntC<8>{}, IntC<2>{}); else fn(IntC<8>{}, IntC<1>{});
+            break;
         case 16: fn(IntC<16>{}, IntC<1>{}); break;
         case 32: fn(IntC<32>{}, IntC<1>{}); break;
         default: fn(IntC<64>{}, IntC<1>{}); break;

@@ -58,11 +58,16 @@ int mzmcts_create(const mzmcts_config* c, mzmcts_engine** out) {
         p.chunks = 2;
     } else if (c->group_width != 0) {
         const int g = c->group_width;
-        if (g < p.group || g > 64 || (g & (g - 1)) != 0) {
+        // half of pow2(A) lanes (4 or 8) with two children per lane: for action counts just above a power of two (9 of 16
+        // lanes busy) the tree kernels run half the wavefronts
+        const bool halved = (g == 4 || g == 8) && 2 * g == p.group && A > g;
+        if (!halved && (g < p.group || g > 64 || (g & (g - 1)) != 0)) {
             delete eng;
-            return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: group_width must be a power of two in [pow2(A), 64]");
+            return fail(nullptr, MZMCTS_ERR_INVALID, "mzmcts_create: group_width must be a power of two in [pow2(A), 64] "
+                                                     "(or pow2(A) / 2 = 4 or 8: two children per lane)");
         }
         p.group = g;
+        if (halved) p.chunks = 2;
     }
     p.links_offset = 16u * static_cast<uint32_t>(A);
     p.block_stride = mz::round_up(32u * static_cast<uint32_t>(A), 64u);

@@ -110,6 +110,30 @@ def test_injected_traces_one_lane_per_tree(eng, oracle, name):
 
 
 @pytest.mark.parametrize("name", TRACE_FILES)
+def test_injected_traces_two_children_per_lane(eng, oracle, name):
+    """group_width = pow2(A) / 2 (4 or 8 lanes, two children per lane) for action counts just above a power of two
+    (TicTacToe: 9 actions on 8 lanes instead of 16): half the wavefronts in the tree kernels.  Every trace tiled 3x
+    (ragged wavefronts): the same bits as the reference's traces -- paths, tie lists, RNG words."""
+    fx = load_golden(name)
+    A = len(fixture_config(fx, None).action_space)
+    full = 1
+    while full < A:
+        full *= 2
+    if full // 2 not in (4, 8) or A <= full // 2:
+        pytest.skip(f"{A} actions: no halved lane group")
+    idx = list(range(len(fx["seed"])))
+    temps = fx["temperature"].tolist()
+    got = run_injected_on_engine(eng, None, fx, idx, temperature=temps, repeat=3, group_width=full // 2)
+    want = run_injected_on_oracle(oracle, fx, idx=idx, temperature=temps)
+    assert got["all_equal"]
+    assert_exact(got, want, where=f"{name} (two children per lane) vs oracle: ")
+    for key in ("noise", "visits", "child_value_sum", "child_prior", "child_reward"):
+        assert np.array_equal(got[key], fx[key]), key
+    assert np.array_equal(got["sim_actions"], fx["sim_actions"][:, :, : int(fx["cfg_S"])])
+    assert np.array_equal(got["sim_ties"], fx["sim_ties"][:, :, : int(fx["cfg_S"])])
+
+
+@pytest.mark.parametrize("name", TRACE_FILES)
 @pytest.mark.parametrize("queue", [40, 256])
 def test_injected_traces_select_queue(eng, oracle, name, queue):
     """select with a wavefront-local queue of trees (mzmcts_set_select_queue): lane groups whose descent ended pick
