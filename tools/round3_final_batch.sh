@@ -9,3 +9,4 @@ tail -3 gpurun_out/gpu_suite.log
 for w in cartpole tictactoe atari84 connect4; do
   python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err && echo "$w: $(cut -c1-150 gpurun_out/bench_$w.json)"
 done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
