@@ -226,6 +226,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
     MZ_STAMP(1);
 
     const ResidentWeights resident = load_resident_weights(units, bias, j);
+    const float transform_reciprocal = inverse_transform_reciprocal();
     int root_entry = 0;
     if constexpr (SPAN == 2) root_entry = window_root_entry(region + lay.off_desc, j);
     // ---- S simulations, entirely inside the CU -----------------------------------------------------
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
             [&]() { backup_fetch_factors<SPAN, PBC2>(round, pbc, pbc2, p.S, sim, j); });
         MZ_STAMP(3);
         float value_f, reward_f;
-        narrow_support_pair(h.value_a, h.value_b, h.reward_a, h.reward_b, net.F, net.support, j, value_f, reward_f);
+        narrow_support_pair<true>(h.value_a, h.value_b, h.reward_a, h.reward_b, net.F, net.support, j, value_f, reward_f,
+                                  transform_reciprocal);
         double prior[1] = {narrow_softmax<SPAN>(h.policy, j < p.A)};
         MZ_STAMP(4);
         const int k_new = sim + 1;

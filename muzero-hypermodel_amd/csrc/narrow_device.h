@@ -218,7 +218,26 @@ __device__ __forceinline__ float narrow_unit(const float4* units, const float* b
     return apply_unit(load_unit<U>(units, bias, j), x);
 }
 
-__device__ __forceinline__ float narrow_elu(float v) { return v > 0.f ? v : elu_negative(v); }
+// expf for arguments that are never positive (ELU's negative side, soft-max terms x - max): the library's sequence --
+// x log2(e) split into a rounded part and a remainder, v_exp_f32, v_ldexp_f32, zero below -103.97 -- without its final
+// select for arguments above 88.7 (the compiled code of the two differs in exactly that select and its compare).
+__device__ __forceinline__ float exp_nonpositive(float x) {
+    const float p = 0x1.715476p+0f * x;
+    const float p_error = __builtin_fmaf(x, 0x1.715476p+0f, -p);
+    const float n = __builtin_rintf(p);
+    const float low = __builtin_fmaf(x, 0x1.4ae0bep-26f, p_error);
+    const float f = (p - n) + low;
+    const float r = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), static_cast<int>(n));
+    return x < -0x1.9d1da0p+6f ? 0.f : r;
+}
+
+// (the exponentials are computed for every lane and selected afterwards -- the empty asm keeps the compiler from wrapping
+//  them in a branch on the selecting condition, which costs more than the few lanes it would spare)
+__device__ __forceinline__ float narrow_elu(float v) {
+    float e = exp_nonpositive(fminf(v, 0.f)) - 1.0f;
+    asm volatile("" : "+v"(e));
+    return v > 0.f ? v : e;
+}
 
 // models.py:137-145 / 161-168: min-max rescale of the first `enc` lanes to [0, 1]; lanes beyond read 0
 __device__ __forceinline__ float narrow_rescale(float raw, int enc, int j) {
@@ -309,17 +328,65 @@ __device__ __forceinline__ NarrowHeads narrow_initial(const float4* units, const
     return h;
 }
 
+// models.py:656-661 (invert the value scaling) with the two library calls of tree_device.h's inverse_value_transform cut
+// down to what its operands need -- the same instructions in the same order, so the same bits:
+//   * sqrtf(1 + w), 1 <= 1 + w: the library's v_sqrt_f32 + one-ulp-down / one-ulp-up residual test, without the scaling
+//     it wraps around operands below 2^-96 and the zero / infinity pass-through;
+//   * r / 0.002f, 0.002 <= r: the division sequence's refined reciprocal of the CONSTANT denominator is computed once
+//     (inverse_transform_reciprocal, from an operand the compiler cannot fold) and a quotient pays the sequence's last
+//     five operations; v_div_scale / v_div_fixup are the identity on these operands.
+__device__ __forceinline__ float inverse_transform_reciprocal() {
+    float c = 0.002f;
+    asm volatile("" : "+v"(c));                  // (the hardware's v_rcp_f32 of it, not a folded constant)
+    const float r0 = __builtin_amdgcn_rcpf(c);
+    const float e = __builtin_fmaf(-c, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float inverse_value_transform_narrow(float x, float reciprocal) {
+    const float u = (fabsf(x) + 1.0f) + 0.001f;
+    const float w = 0.004f * u;
+    const float a = 1.0f + w;
+    float root;
+    {
+        const float s = __builtin_amdgcn_sqrtf(a);
+        const float down = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+        const float up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+        const float r_down = __builtin_fmaf(-down, s, a);
+        const float r_up = __builtin_fmaf(-up, s, a);
+        root = 0.f >= r_down ? down : s;
+        root = 0.f < r_up ? up : root;
+    }
+    const float r = root - 1.0f;
+    float q;
+    {
+        const float c = 0.002f;
+        const float q0 = r * reciprocal;
+        const float e2 = __builtin_fmaf(-c, q0, r);
+        const float q1 = __builtin_fmaf(e2, reciprocal, q0);
+        const float e3 = __builtin_fmaf(-c, q1, r);
+        q = __builtin_fmaf(e3, reciprocal, q1);
+    }
+    const float y = q * q - 1.0f;
+    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return sgn * y;
+}
+
 // models.py:641-662 support_to_scalar for two logit vectors held in registers (element j in `a`, 16 + j in
 // `b`); the two reductions are interleaved.  Every lane of the row receives both results.
+// CUT: the decode ends in inverse_value_transform_narrow (`reciprocal` from inverse_transform_reciprocal)
+template <bool CUT = false>
 __device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra, float rb, int F, int support, int j,
-                                                    float& value, float& reward) {
+                                                    float& value, float& reward, float reciprocal = 0.f) {
     const bool in_a = j < F, in_b = kRow + j < F;
     const float xva = in_a ? va : -INFINITY, xvb = in_b ? vb : -INFINITY;
     const float xra = in_a ? ra : -INFINITY, xrb = in_b ? rb : -INFINITY;
     float mv = fmaxf(xva, xvb), mr = fmaxf(xra, xrb);
     MZ_BUTTERFLY(kRow, kRow, (mv = fmaxf(mv, partner<M>(mv)), mr = fmaxf(mr, partner<M>(mr))));
-    const float eva = in_a ? expf(xva - mv) : 0.f, evb = in_b ? expf(xvb - mv) : 0.f;
-    const float era = in_a ? expf(xra - mr) : 0.f, erb = in_b ? expf(xrb - mr) : 0.f;
+    float tva = exp_nonpositive(xva - mv), tvb = exp_nonpositive(xvb - mv);
+    float tra = exp_nonpositive(xra - mr), trb = exp_nonpositive(xrb - mr);
+    asm volatile("" : "+v"(tva), "+v"(tvb), "+v"(tra), "+v"(trb));
+    const float eva = in_a ? tva : 0.f, evb = in_b ? tvb : 0.f;
+    const float era = in_a ? tra : 0.f, erb = in_b ? trb : 0.f;
     float sv = eva + evb, sr = era + erb;
     MZ_BUTTERFLY(kRow, kRow, (sv = sv + partner<M>(sv), sr = sr + partner<M>(sr)));
     const float iv = 1.0f / sv, ir = 1.0f / sr;
@@ -327,8 +394,13 @@ __device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra
     float av = fa * (eva * iv) + fb * (evb * iv);
     float ar = fa * (era * ir) + fb * (erb * ir);
     MZ_BUTTERFLY(kRow, kRow, (av = av + partner<M>(av), ar = ar + partner<M>(ar)));
-    value = inverse_value_transform(av);
-    reward = inverse_value_transform(ar);
+    if constexpr (CUT) {
+        value = inverse_value_transform_narrow(av, reciprocal);
+        reward = inverse_value_transform_narrow(ar, reciprocal);
+    } else {
+        value = inverse_value_transform(av);
+        reward = inverse_value_transform(ar);
+    }
 }
 
 // fp32 softmax over the lanes with valid == true (Node.expand, self_play.py:461-463), widened like .tolist()
@@ -337,7 +409,9 @@ template <int SPAN = kRow>
 __device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
     float m = valid ? logit : -INFINITY;
     MZ_BUTTERFLY(SPAN, SPAN, m = fmaxf(m, partner<M>(m)));
-    const float e = valid ? expf(logit - m) : 0.f;
+    float t = exp_nonpositive(logit - m);
+    asm volatile("" : "+v"(t));
+    const float e = valid ? t : 0.f;
     float s = e;
     MZ_BUTTERFLY(SPAN, SPAN, s = s + partner<M>(s));
     return static_cast<double>(e * (1.0f / s));
