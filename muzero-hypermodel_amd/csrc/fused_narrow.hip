@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kNarrowMaxThreads) __attribute__((amdgpu_waves_per_
         float value_f, reward_f;
         narrow_support_pair<true>(h.value_a, h.value_b, h.reward_a, h.reward_b, net.F, net.support, j, value_f, reward_f,
                                   transform_reciprocal);
-        double prior[1] = {narrow_softmax<SPAN>(h.policy, j < p.A)};
+        double prior[1] = {narrow_softmax<SPAN, true>(h.policy, j < p.A)};
         MZ_STAMP(4);
         const int k_new = sim + 1;
         if constexpr (SPAN == 2) {

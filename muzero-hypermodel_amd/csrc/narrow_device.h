@@ -231,6 +231,18 @@ __device__ __forceinline__ float exp_nonpositive(float x) {
     return x < -0x1.9d1da0p+6f ? 0.f : r;
 }
 
+// 1.0f / d for a sum of soft-max terms (1 <= d <= 32: the term of the maximum is 1): the division sequence without
+// v_div_scale / v_div_fixup, which are the identity on such operands -- the same seven operations, the same bits
+__device__ __forceinline__ float reciprocal_of_sum(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e, r0, r0);
+    const float e2 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(e2, r1, r1);
+    const float e3 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(e3, r1, q1);
+}
+
 // (the exponentials are computed for every lane and selected afterwards -- the empty asm keeps the compiler from wrapping
 //  them in a branch on the selecting condition, which costs more than the few lanes it would spare)
 __device__ __forceinline__ float narrow_elu(float v) {
@@ -389,7 +401,7 @@ __device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra
     const float era = in_a ? tra : 0.f, erb = in_b ? trb : 0.f;
     float sv = eva + evb, sr = era + erb;
     MZ_BUTTERFLY(kRow, kRow, (sv = sv + partner<M>(sv), sr = sr + partner<M>(sr)));
-    const float iv = 1.0f / sv, ir = 1.0f / sr;
+    const float iv = CUT ? reciprocal_of_sum(sv) : 1.0f / sv, ir = CUT ? reciprocal_of_sum(sr) : 1.0f / sr;
     const float fa = static_cast<float>(j - support), fb = static_cast<float>(kRow + j - support);
     float av = fa * (eva * iv) + fb * (evb * iv);
     float ar = fa * (era * ir) + fb * (erb * ir);
@@ -405,7 +417,8 @@ __device__ __forceinline__ void narrow_support_pair(float va, float vb, float ra
 
 // fp32 softmax over the lanes with valid == true (Node.expand, self_play.py:461-463), widened like .tolist()
 // SPAN: lanes 0 .. SPAN-1 hold every valid entry, and only they receive a meaningful result
-template <int SPAN = kRow>
+// CUT: 1 / sum by reciprocal_of_sum (at least one valid entry among the SPAN lanes)
+template <int SPAN = kRow, bool CUT = false>
 __device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
     float m = valid ? logit : -INFINITY;
     MZ_BUTTERFLY(SPAN, SPAN, m = fmaxf(m, partner<M>(m)));
@@ -414,7 +427,7 @@ __device__ __forceinline__ double narrow_softmax(float logit, bool valid) {
     const float e = valid ? t : 0.f;
     float s = e;
     MZ_BUTTERFLY(SPAN, SPAN, s = s + partner<M>(s));
-    return static_cast<double>(e * (1.0f / s));
+    return static_cast<double>(e * (CUT ? reciprocal_of_sum(s) : 1.0f / s));
 }
 
 // ---- tree in LDS with the per-child value term ---------------------------------------------------------
