@@ -68,6 +68,23 @@ def test_create_rejects_bad_configs(native):
     assert lib.mzmcts_create(ctypes.byref(cfg), ctypes.byref(handle)) == native.ERR_INVALID
 
 
+def test_downsample_launch_rejects_what_it_does_not_cover(native):
+    """mzmcts_downsample_cnn's argument checks run before anything touches the GPU: shapes beyond config #5's family, a
+    hidden width whose LDS plan does not fit a CU, misaligned frames and null pointers come back as MZMCTS_ERR_INVALID
+    (the caller then keeps its convolution library); an empty batch of a covered shape is MZMCTS_OK."""
+    lib = native.load()
+    ptr = 0x10000                                  # never dereferenced: every call below returns before a launch
+
+    def call(batch=0, c=4, h=84, w=84, mid=10, k1=12, cout=16, oh=6, ow=6, x=ptr, w1=ptr):
+        return lib.mzmcts_downsample_cnn(x, batch, c, h, w, w1, ptr, mid, k1, ptr, ptr, cout, oh, ow, ptr, None)
+
+    assert call() == 0
+    assert call(c=3) == native.ERR_INVALID and call(h=96, w=96) == native.ERR_INVALID
+    assert call(k1=8) == native.ERR_INVALID and call(cout=17) == native.ERR_INVALID and call(oh=9) == native.ERR_INVALID
+    assert call(mid=3) == native.ERR_INVALID and call(mid=11) == native.ERR_INVALID      # 11: 164 KB of LDS
+    assert call(x=ptr + 4) == native.ERR_INVALID and call(x=None) == native.ERR_INVALID and call(batch=-1) == native.ERR_INVALID
+
+
 @pytest.mark.parametrize("seed", [0, 1, 12345, 2**32 - 1])
 def test_host_rng_matches_numpy_fixture(native, golden, seed):
     fx = golden("g7_numpy_rng")
