@@ -80,7 +80,10 @@ REFERENCE_TIMING, REFERENCE_TIMING_HOST = _load_rho()
 # envs 4.94 -> 5.67 M, the 84x84 config 32768 envs 26.6 -> 27.9 M.
 WORKLOADS = {
     "cartpole": dict(envs=4096, baseline_config=2, groups=2),
-    "tictactoe": dict(envs=65536, baseline_config=3, groups=2),
+    # fused_step: expand_backup of a simulation and the descent of the next in one launch (MZ_FUSED_STEP, engine.py) --
+    # measured on one box, three alternating pairs: 239.6 / 244.2 / 244.5 M without, 245.3 / 250.8 / 253.4 M with it;
+    # config #5 the same either way, Connect4 6.82 M without against 6.71 M with it: on for TicTacToe only
+    "tictactoe": dict(envs=65536, baseline_config=3, groups=2, fused_step=True),
     "connect4": dict(envs=8192, baseline_config=4, groups=2),
     # (one group: a move is 42 ms of GPU work, the host's turn between moves is noise, and two half-size groups run
     #  every kernel at half its batch -- measured 38.9 M against 36.9 M simulations/s; TicTacToe needs its two groups
@@ -129,6 +132,8 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.groups <= 0:
         args.groups = WORKLOADS[args.workload]["groups"]
+    if WORKLOADS[args.workload].get("fused_step"):
+        os.environ.setdefault("MZ_FUSED_STEP", "on")     # (read by every engine this process creates)
     return args
 
 

@@ -20,6 +20,7 @@ HIP library and there is no fallback if it is missing.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -73,8 +74,9 @@ class BatchedMCTS:
         self._fc_flat = None
         self.fused_hidden_in_lds = True
         # lock-step loop: expand_backup + next select in one launch (mzmcts_expand_backup_select).  Bit-identical and one
-        # launch fewer per simulation, but not faster where measured: off by default
-        self.fused_step = False
+        # launch fewer per simulation; faster only at many envs of a shallow search (TicTacToe 65536 envs: +2-4 %; config
+        # #5 unchanged, Connect4 -2 %): off unless MZ_FUSED_STEP=on (bench.py's TicTacToe workload sets it)
+        self.fused_step = os.environ.get("MZ_FUSED_STEP", "off") == "on"
         self._device_noise = False
 
         with torch.cuda.device(self.device):
@@ -310,7 +312,7 @@ class BatchedMCTS:
         mzmcts_board_tower_gathered): no [E, channels + 1, h, w] tensor between the descent and the network."""
         ok = getattr(self, "_pool_ok", None)
         if ok is None or ok[0] is not model:
-            usable = (not self.fused_step and self._planes_path(model) and hasattr(model, "recurrent_inference_from_pool")
+            usable = (self._planes_path(model) and hasattr(model, "recurrent_inference_from_pool")
                       and model.pool_towers_supported(self.E, self.device, self.state_shape))
             self._pool_ok = ok = (model, usable)
         return ok[1]
@@ -355,7 +357,9 @@ class BatchedMCTS:
         for s in range(done, self.S):
             value, reward, policy, _ = self._infer(model)
             if s + 1 < self.S and self.fused_step:
-                if self._planes_path(model):
+                if self._pool_path(model):
+                    self.expand_backup_select(value, reward, policy, None, gather=False)   # the towers gather for themselves
+                elif self._planes_path(model):
                     self.expand_backup_select_planes(value, reward, policy)
                 else:
                     self.expand_backup_select(value, reward, policy, None)

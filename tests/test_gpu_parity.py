@@ -925,3 +925,45 @@ def test_many_env_actor_plays_expert_and_random_opponents(eng, models_mod, pkg):
         assert set(a) == set(b)
         for k in a:
             assert a[k] == pytest.approx(b[k], abs=RESNET_TOL["value_tol"]), k
+
+
+@pytest.mark.parametrize("game,use_graph", [("tictactoe", False), ("tictactoe", True), ("connect4", True)])
+def test_fused_step_with_towers_gathering_from_the_pool(eng, models_mod, monkeypatch, game, use_graph):
+    """MZ_FUSED_STEP=on (expand_backup of a simulation and the descent of the next in one launch) on the path where the
+    towers read their input from the hidden-state pool: the same noise, visit counts, value sums, bounds, sampled actions
+    and tree as the two-launch loop, over three moves (an eager one, the capturing one, a replay)."""
+    import importlib
+    from parity_helpers import synthetic_model
+    config = importlib.import_module(f"muzero-hypermodel_amd.games.{game}").MuZeroConfig()
+    if game == "connect4":
+        config.num_simulations = 40
+    model, _ = synthetic_model(models_mod, config, "cuda")
+    A = len(config.action_space)
+    E = 150
+    rs = np.random.RandomState(21)
+    c, h, w = config.observation_shape
+    obs = torch.from_numpy(rs.randint(-1, 2, (E, c, h, w)).astype(np.float32)).cuda()
+    legal = np.zeros((E, A), np.int32)
+    num_legal = rs.randint(1, A + 1, E).astype(np.int32)
+    for e in range(E):
+        legal[e, :num_legal[e]] = np.sort(rs.permutation(A)[:num_legal[e]])
+    to_play = rs.randint(0, 2, E).astype(np.int32)
+    seeds = list(range(900, 900 + E))
+    runs = {}
+    for mode in ("off", "on"):
+        monkeypatch.setenv("MZ_FUSED_STEP", mode)
+        engine = eng.BatchedMCTS(config, E, seeds=seeds, use_graph=use_graph)
+        assert engine.fused_step == (mode == "on") and engine._pool_path(model)
+        moves = []
+        for _ in range(3):
+            st = engine.search(model, obs, legal, to_play, True, num_legal=num_legal)
+            actions, _ = engine.sample_actions(1.0)
+            moves.append(({k: v.copy() for k, v in st.items()}, engine.noise.copy(), actions.copy(), engine.export_tree(E - 1)))
+        engine.close()
+        runs[mode] = moves
+    for (a_st, a_noise, a_act, a_tree), (b_st, b_noise, b_act, b_tree) in zip(runs["off"], runs["on"]):
+        assert np.array_equal(a_noise, b_noise) and np.array_equal(a_act, b_act)
+        for key in a_st:
+            assert np.array_equal(a_st[key], b_st[key]), key
+        for key in a_tree:
+            assert np.array_equal(a_tree[key], b_tree[key]), f"tree {key}"
