@@ -74,9 +74,10 @@ class BatchedMCTS:
         self._fc_flat = None
         self.fused_hidden_in_lds = True
         # lock-step loop: expand_backup + next select in one launch (mzmcts_expand_backup_select).  Bit-identical and one
-        # launch fewer per simulation; faster only at many envs of a shallow search (TicTacToe 65536 envs: +2-4 %; config
-        # #5 unchanged, Connect4 -2 %): off unless MZ_FUSED_STEP=on (bench.py's TicTacToe workload sets it)
-        self.fused_step = os.environ.get("MZ_FUSED_STEP", "off") == "on"
+        # launch fewer per simulation; measured faster at many envs (TicTacToe, 2 x 32768 envs: +2-4 %; config #5 at 32768
+        # envs: unchanged) and slower at few (Connect4, 2 x 4096 envs: -2 %): MZ_FUSED_STEP=on / off, default by env count
+        mode = os.environ.get("MZ_FUSED_STEP", "auto")
+        self.fused_step = mode == "on" or (mode != "off" and self.E >= 16384)
         self._device_noise = False
 
         with torch.cuda.device(self.device):
