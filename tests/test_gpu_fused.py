@@ -237,6 +237,10 @@ def fc_variant(name):
         cfg = cartpole_config()
         cfg.players = list(range(2))
         cfg.num_simulations = 45
+    elif name == "narrow_pair_s100":
+        # two actions, more simulations than the rows-of-64 exploration table covers (triangular table, deeper windows)
+        cfg = cartpole_config()
+        cfg.num_simulations = 100
     elif name in ("narrow_2p", "narrow_1p"):
         # shapes the narrow (register-resident) kernel accepts besides cartpole's own
         cfg = cartpole_config()
@@ -258,7 +262,7 @@ def fc_variant(name):
 
 @pytest.mark.parametrize("name,group", [("tictactoe_fc", 16), ("tictactoe_fc", 0), ("connect4_fc", 16),
                                         ("cartpole_deep", 16), ("cartpole_deep", 4), ("narrow_2p", 16),
-                                        ("narrow_1p", 16), ("narrow_pair_2p", 16)])
+                                        ("narrow_1p", 16), ("narrow_pair_2p", 16), ("narrow_pair_s100", 16)])
 def test_fused_other_fc_shapes(eng, models_mod, oracle, name, group):
     from parity_helpers import synthetic_model
     cfg = fc_variant(name)
