@@ -137,6 +137,60 @@ def test_narrow_kernel_forms_are_bit_identical(eng, models_mod, monkeypatch, tab
     assert np.array_equal(a_pool, b_pool)
 
 
+@pytest.mark.parametrize("shape", ["ties_everywhere", "one_long_chain", "chain_with_values"])
+def test_narrow_kernel_on_extreme_trees(eng, models_mod, shape):
+    """Trees the trained network never grows, fused against lock-step, bit for bit (100 simulations):
+      ties_everywhere    all-zero weights: every select_child is a tie, every level of every descent draws from the tree's
+                         RNG stream (the windowed descent stops at each of them);
+      one_long_chain     a policy head that always prefers action 0: the tree is one chain, simulation s descends s + 1
+                         levels -- up to 25 windows per descent, backups of up to seven 16-level rounds (the visit count
+                         of the node above a round's top level comes from the path);
+      chain_with_values  the same with value / reward heads that spread the min-max bounds (the normaliser's short form
+                         on every level of the chain)."""
+    config = cartpole_config()
+    config.num_simulations = 100
+    model = models_mod.MuZeroNetwork(config)
+    sd = {k: torch.zeros_like(v) for k, v in model.state_dict().items()}
+    if shape != "ties_everywhere":
+        sd["prediction_policy_network.module.2.bias"] = torch.tensor([9.0, -9.0])
+    if shape == "chain_with_values":
+        g = torch.Generator().manual_seed(4)
+        for key in ("prediction_value_network.module.2.bias", "dynamics_reward_network.module.2.bias",
+                    "prediction_value_network.module.0.weight", "dynamics_encoded_state_network.module.0.weight",
+                    "dynamics_encoded_state_network.module.2.weight", "prediction_value_network.module.2.weight"):
+            sd[key] = torch.randn(sd[key].shape, generator=g) * 0.7
+    model.set_weights(sd)
+    model.cuda().eval()
+    E = 37
+    rs = np.random.RandomState(2)
+    obs = rs.uniform(-0.05, 0.05, (E, 1, 1, 4)).astype(np.float32)
+    legal, to_play = [[0, 1]] * E, [0] * E
+    seeds = [int(s) for s in rs.randint(0, 2**31 - 1, E)]
+    runs = []
+    for fused in (False, True):
+        engine = eng.BatchedMCTS(config, E, seeds=seeds, group_width=16)
+        engine.configure_fused_fc(model)
+        engine.set_fused_options("narrow")
+        run = engine.search_fused if fused else engine.search_lockstep_fc
+        st = copy_stats(run(torch.from_numpy(obs), legal, to_play, True))
+        actions, _ = engine.sample_actions(1.0)
+        runs.append((st, actions.copy(), engine.export_tree(0), engine.export_tree(E - 1), engine.pool.clone().cpu().numpy()))
+        engine.close()
+    a, b = runs
+    for key in a[0]:
+        assert np.array_equal(a[0][key], b[0][key]), key
+    assert np.array_equal(a[1], b[1])
+    for ta, tb in ((a[2], b[2]), (a[3], b[3])):
+        for key in ta:
+            assert np.array_equal(ta[key], tb[key]), f"tree {key}"
+    assert np.array_equal(a[4], b[4])
+    depth = a[0]["max_tree_depth"]
+    if shape == "ties_everywhere":
+        assert (a[0]["tie_words"] >= config.num_simulations).all() if "tie_words" in a[0] else True
+    else:
+        assert depth.max() >= 60, depth.max()          # the chain: far beyond one window / one backup round
+
+
 @pytest.mark.parametrize("group,variant", [(4, "generic"), (16, "narrow")])
 def test_fused_vs_reference_traces(eng, models_mod, group, variant):
     config = cartpole_config()
