@@ -341,7 +341,7 @@ def test_board_column_heads_are_bit_identical_to_the_mfma_heads(pkg, monkeypatch
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("batch,mid_out", [(5, (10, 16)), (300, (10, 16)), (3, (7, 12))])
+@pytest.mark.parametrize("batch,mid_out", [(5, (10, 16)), (300, (10, 16)), (3, (7, 12)), (1, (10, 16)), (777, (10, 16))])
 def test_downsample_cnn_launch_equals_the_torch_layers(pkg, monkeypatch, batch, mid_out):
     """include/mzmcts.h mzmcts_downsample_cnn (the seven layers of models.py:278-297 in one launch, config #5's 4 x 84 x 84
     frames) against the same layers in float64 on the CPU and against the convolution library's float32 path: the kernel's
@@ -369,6 +369,8 @@ def test_downsample_cnn_launch_equals_the_torch_layers(pkg, monkeypatch, batch, 
     err_kernel, err_library = (g - e).abs().max().item(), (l - e).abs().max().item()
     assert err_kernel <= 2e-6 * scale + 1e-7, (err_kernel, err_library, scale)
     assert torch.allclose(got, library, rtol=2e-5, atol=2e-6 * scale)
+    if batch < 3:
+        return
     # a NaN in a frame reaches that frame's outputs and no other frame's
     x[1, 0, 10, 10] = float("nan")
     with torch.no_grad():
