@@ -644,6 +644,33 @@ constexpr int kColBoardStride = 148;          // floats between two boards' [9][
 constexpr int kColActStride = 12;             // floats between two boards' 17th-channel values [9]
 constexpr int kColWaveFloats = 16 * (kColBoardStride + kColActStride) + 32;   // + the boards' input rows (16 pointers)
 
+// Where value idx = lane + 64 it of a wavefront's NCHW boards ([board][16 channels][P positions]) lives in the
+// [board][position][channel] LDS image (boards STRIDE floats apart).  64 * 9 = 576 is a whole number of boards both for
+// P = 9 (four) and for P = 36 (one): nine iterations later the same (channel, position) of a board further on -- so a lane
+// computes nine offsets once and every later access adds a compile-time constant (an instruction offset) instead of
+// two divisions.
+template <int P, int STRIDE>
+struct PlaneWalk {
+    static constexpr int ROW = 16 * P, BOARDS_PER_9 = 576 / ROW;
+    static_assert(576 % ROW == 0, "nine iterations = whole boards");
+    int base[9];    // LDS float offset of iterations 0..8
+    __device__ __forceinline__ int at(int it) const { return base[it % 9] + (it / 9) * BOARDS_PER_9 * STRIDE; }
+};
+template <int P, int STRIDE>
+__device__ __forceinline__ PlaneWalk<P, STRIDE> plane_walk(int lane) {
+    PlaneWalk<P, STRIDE> w;
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+        const int idx = lane + 64 * it;
+        const int q = idx / (16 * P), cp = idx - q * (16 * P);
+        const int c = cp / P, p0 = cp - c * P;
+        w.base[it] = q * STRIDE + p0 * 16 + c;
+    }
+    return w;
+}
+using ColsPlaneWalk = PlaneWalk<9, kColBoardStride>;
+__device__ __forceinline__ ColsPlaneWalk cols_plane_walk(int lane) { return plane_walk<9, kColBoardStride>(lane); }
+
 // Orders this wavefront's LDS writes before its following LDS reads of other lanes' data; no other wavefront is involved.
 __device__ __forceinline__ void cols_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -857,22 +884,24 @@ __global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(
                               : x + static_cast<size_t>(b) * cin0 * P;
         in_row[lane] = row;
     }
+    static_assert(P == 9 && ROW == 144, "ColsPlaneWalk is written for 3 x 3 boards");
+    const ColsPlaneWalk walk = cols_plane_walk(lane);
     {
         float v[FILL];
+        int q9[9], cp9[9];                                          // (board, offset inside the board) of iterations 0..8
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int idx = lane + 64 * it;
+            q9[it] = idx / ROW;
+            cp9[it] = idx - q9[it] * ROW;
+        }
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {                         // idx = (board q, channel c, position p), NCHW order
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const float* row = in_row[q];
-            v[it] = row ? row[cp] : 0.f;
+            const float* row = in_row[q9[it % 9] + 4 * (it / 9)];   // (64 * 9 = 4 * ROW: see ColsPlaneWalk)
+            v[it] = row ? row[cp9[it % 9]] : 0.f;
         }
 #pragma unroll
-        for (int it = 0; it < FILL; ++it) {
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const int c = cp / P, p0 = cp - c * P;
-            xw[q * kColBoardStride + p0 * 16 + c] = v[it];
-        }
+        for (int it = 0; it < FILL; ++it) xw[walk.at(it)] = v[it];
 #pragma unroll
         for (int it = 0; it < (16 * P + 63) / 64; ++it) {
             const int idx = lane + 64 * it;
@@ -896,12 +925,7 @@ __global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(
     auto export_planes = [&](float* out) {                          // NCHW [batch][16][P]: consecutive lanes, consecutive addresses
         float v[FILL];
 #pragma unroll
-        for (int it = 0; it < FILL; ++it) {
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const int c = cp / P, p0 = cp - c * P;
-            v[it] = xw[q * kColBoardStride + p0 * 16 + c];
-        }
+        for (int it = 0; it < FILL; ++it) v[it] = xw[walk.at(it)];
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {
             const int idx = lane + 64 * it;
@@ -1084,21 +1108,18 @@ __global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(
                               : x + static_cast<size_t>(b) * cin0 * P;
         in_row[lane] = row;
     }
+    static_assert(ROW == 576, "nine iterations of 64 lanes = one board (PlaneWalk)");
+    const PlaneWalk<P, BS> walk = plane_walk<P, BS>(lane);
     {
         float v[FILL];
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {                         // idx = (board q, channel c, position p), NCHW order
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const float* row = in_row[q];
-            v[it] = row ? row[cp] : 0.f;
+            const float* row = in_row[it / 9];                      // (board it / 9, offset lane + 64 (it % 9) inside it)
+            v[it] = row ? row[lane + 64 * (it % 9)] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const int c = cp / P, p0 = cp - c * P;
-            xw[q * BS + p0 * 16 + c] = v[it];
+            xw[walk.at(it)] = v[it];
         }
         for (int idx = lane; idx < BPW * P; idx += 64) {
             const int q = idx / P, p0 = idx - q * P;
@@ -1125,12 +1146,7 @@ __global__ __launch_bounds__(64 * kColWaves) __attribute__((amdgpu_waves_per_eu(
     auto export_planes = [&](float* out) {
         float v[FILL];
 #pragma unroll
-        for (int it = 0; it < FILL; ++it) {
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const int c = cp / P, p0 = cp - c * P;
-            v[it] = xw[q * BS + p0 * 16 + c];
-        }
+        for (int it = 0; it < FILL; ++it) v[it] = xw[walk.at(it)];
 #pragma unroll
         for (int it = 0; it < FILL; ++it) {
             const int idx = lane + 64 * it;
@@ -1294,13 +1310,9 @@ __global__ __launch_bounds__(64 * kColWaves) void board_heads_cols_kernel(HeadsC
             const int idx = lane + 64 * it;
             v[it] = idx < n_boards * ROW ? x[static_cast<size_t>(b0) * ROW + idx] : 0.f;
         }
+        const ColsPlaneWalk walk = cols_plane_walk(lane);
 #pragma unroll
-        for (int it = 0; it < FILL; ++it) {
-            const int idx = lane + 64 * it;
-            const int q = idx / ROW, cp = idx - q * ROW;
-            const int c = cp / P, p0 = cp - c * P;
-            xw[q * kColBoardStride + p0 * 16 + c] = v[it];
-        }
+        for (int it = 0; it < FILL; ++it) xw[walk.at(it)] = v[it];
     }
     cols_wave_sync();
     f32x4 y0[P];
